@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI in include/ganet_hip.h (libganet_hip.so).
+
+The product path: `lib()` loads ganet_amd/libganet_hip.so -- the gfx950 build made by
+`ganet_amd.build.build_hip()` / `__graft_entry__.build()` -- and raises if it is
+missing.  There is no CPU fallback.  (`CApi` takes an explicit path so the test-suite
+can bind the same ABI to the lockstep kernel emulator under tests/hipsim.)
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libganet_hip.so"
+ABI_VERSION = 1
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+# name -> argument types (return type is always int unless listed in _RET)
+_PROTOS = {
+    "ganet_abi_version": [],
+    "ganet_is_simulator": [],
+    "ganet_set_option": [ctypes.c_char_p, _I],
+    "ganet_sga_scan_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ganet_sga_forward": [_P] * 8 + [_I] * 5 + [_P],
+    "ganet_sga_backward_dir": [_P] * 7 + [_I] * 7 + [_P],
+    "ganet_sga_backward": [_P] * 13 + [_I] * 5 + [_P],
+    "ganet_sga_forward_compat": [_P] * 8 + [_I] * 5 + [_P],
+    "ganet_sga_backward_compat": [_P] * 15 + [_I] * 5 + [_P],
+    "ganet_lga_forward": [_P] * 3 + [_I] * 5 + [_P],
+    "ganet_lga_backward": [_P] * 5 + [_I] * 6 + [_P],
+    "ganet_cost_volume_forward": [_P] * 3 + [_I] * 5 + [_P],
+    "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],
+    "ganet_disparity_regression_forward": [_P] * 2 + [_I] * 4 + [_P],
+    "ganet_disparity_regression_backward": [_P] * 2 + [_I] * 4 + [_P],
+    "ganet_selftest_dpp": [_P, _P, _P],
+}
+EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])
+
+
+class GanetError(RuntimeError):
+    pass
+
+
+class CApi:
+    """Thin, typed view of one loaded libganet_*.so."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise GanetError(
+                f"{path} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        self.path = path
+        self._lib = ctypes.CDLL(path)
+        self._lib.ganet_last_error.restype = ctypes.c_char_p
+        self._lib.ganet_last_error.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(self._lib, name)
+            fn.argtypes = args
+            fn.restype = _I
+        got = self._lib.ganet_abi_version()
+        if got != ABI_VERSION:
+            raise GanetError(f"{path}: ABI version {got}, expected {ABI_VERSION}")
+        self.is_simulator = bool(self._lib.ganet_is_simulator())
+
+    def last_error(self):
+        return self._lib.ganet_last_error().decode("utf-8", "replace")
+
+    def call(self, name, *args):
+        rc = getattr(self._lib, name)(*args)
+        if rc != 0:
+            raise GanetError(f"{name} failed ({rc}): {self.last_error()}")
+
+    def set_option(self, name, value):
+        self.call("ganet_set_option", name.encode(), int(value))
+
+
+_LIB = None
+_LOCK = threading.Lock()
+
+
+def lib_path():
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def lib():
+    """The process-wide gfx950 library; raises GanetError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        with _LOCK:
+            if _LIB is None:
+                _LIB = CApi(lib_path())
+    return _LIB

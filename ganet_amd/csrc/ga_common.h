@@ -1,0 +1,151 @@
+// ga_common.h -- shared device helpers for the gfx950 guided-aggregation kernels.
+//
+// Built two ways from the SAME kernel source:
+//   * hipcc --offload-arch=gfx950            -> libganet_hip.so (the product)
+//   * g++ -DGA_HIPSIM -include hipsim.h       -> tests/hipsim/libganet_sim.so, a
+//     lockstep wave64 emulator used ONLY by the CPU test-suite to check kernel
+//     logic (indexing, DPP lane patterns, reductions) where no GPU exists.
+// Wavefront = 64 lanes everywhere; cross-lane traffic is DPP within 16-lane rows.
+#pragma once
+
+#if defined(GA_HIPSIM)
+#include "hipsim.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <math.h>
+#include <stdint.h>
+
+#define GA_DEV __device__ __forceinline__
+
+namespace ga {
+
+typedef long long i64;
+
+#if defined(GA_HIPSIM)
+struct alignas(16) f4 { float x, y, z, w; };
+#else
+typedef float4 f4;
+#endif
+
+GA_DEV float f4_get(const f4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+GA_DEV void f4_set(f4 &v, int k, float a)
+{
+  if (k == 0) v.x = a; else if (k == 1) v.y = a; else if (k == 2) v.z = a; else v.w = a;
+}
+
+GA_DEV int lane_id()
+{
+#if defined(GA_HIPSIM)
+  return hipsim::lane_id();
+#else
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#endif
+}
+
+// ---- DPP (data-parallel primitives) ---------------------------------------
+// dpp_ctrl encodings (LLVM SIDefines.h DppCtrl): quad_perm 0x00-0xFF,
+// row_shl:n 0x100+n, row_shr:n 0x110+n, row_mirror 0x140, row_half_mirror 0x141.
+// row_shr:1 -> lane i receives lane i-1 of its 16-lane row; row_shl:1 -> lane i+1.
+// A lane whose source falls outside the row keeps `old` (bound_ctrl = false).
+enum : int {
+  DPP_QP_XOR1 = 0xB1,   // quad_perm [1,0,3,2]
+  DPP_QP_XOR2 = 0x4E,   // quad_perm [2,3,0,1]
+  DPP_ROW_SHL1 = 0x101,
+  DPP_ROW_SHR1 = 0x111,
+  DPP_ROW_MIRROR = 0x140,
+  DPP_ROW_HALF_MIRROR = 0x141
+};
+
+#if !defined(GA_HIPSIM) && defined(GA_NO_DPP)
+// Debug variant (libganet_hip_nodpp.so): same lane patterns through ds_bpermute.
+template <int CTRL> GA_DEV int dpp_src_lane(int lane, bool &valid)
+{
+  const int row = lane & ~15, r = lane & 15;
+  valid = true;
+  if (CTRL == DPP_QP_XOR1) return lane ^ 1;
+  if (CTRL == DPP_QP_XOR2) return lane ^ 2;
+  if (CTRL == DPP_ROW_SHL1) { valid = r < 15; return lane + 1; }
+  if (CTRL == DPP_ROW_SHR1) { valid = r > 0; return lane - 1; }
+  if (CTRL == DPP_ROW_MIRROR) return row + (15 - r);
+  /* DPP_ROW_HALF_MIRROR */ return (lane & ~7) + (7 - (lane & 7));
+}
+template <int CTRL> GA_DEV int dpp_i(int old, int src)
+{
+  bool valid;
+  const int sl = dpp_src_lane<CTRL>(lane_id(), valid);
+  const int v = __builtin_amdgcn_ds_bpermute((valid ? sl : 0) << 2, src);
+  return valid ? v : old;
+}
+#elif !defined(GA_HIPSIM)
+template <int CTRL> GA_DEV int dpp_i(int old, int src)
+{
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+#else
+template <int CTRL> GA_DEV int dpp_i(int old, int src) { return hipsim::update_dpp(old, src, CTRL); }
+#endif
+
+GA_DEV int f2i(float f) { union { float f; int i; } u; u.f = f; return u.i; }
+GA_DEV float i2f(int i) { union { float f; int i; } u; u.i = i; return u.f; }
+template <int CTRL> GA_DEV float dpp_f(float old, float src) { return i2f(dpp_i<CTRL>(f2i(old), f2i(src))); }
+
+// ---- segment ops: a "segment" is GD consecutive lanes (GD in 1,2,4,8,16) that
+// together own one scanline; lg = lane % GD.
+// value held by the previous / next lane of the segment; segment ends keep `old`
+template <int GD> GA_DEV float seg_from_prev(float old, float src, int lg)
+{
+  if (GD == 1) return old;
+  const float r = dpp_f<DPP_ROW_SHR1>(old, src);
+  return lg == 0 ? old : r;
+}
+template <int GD> GA_DEV float seg_from_next(float old, float src, int lg)
+{
+  if (GD == 1) return old;
+  const float r = dpp_f<DPP_ROW_SHL1>(old, src);
+  return lg == GD - 1 ? old : r;
+}
+template <int GD> GA_DEV float seg_allmax(float v)
+{
+  if (GD >= 2) v = fmaxf(v, dpp_f<DPP_QP_XOR1>(v, v));
+  if (GD >= 4) v = fmaxf(v, dpp_f<DPP_QP_XOR2>(v, v));
+  if (GD >= 8) v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v, v));
+  if (GD >= 16) v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v, v));
+  return v;
+}
+template <int GD> GA_DEV float seg_allsum(float v)
+{
+  if (GD >= 2) v += dpp_f<DPP_QP_XOR1>(v, v);
+  if (GD >= 4) v += dpp_f<DPP_QP_XOR2>(v, v);
+  if (GD >= 8) v += dpp_f<DPP_ROW_HALF_MIRROR>(v, v);
+  if (GD >= 16) v += dpp_f<DPP_ROW_MIRROR>(v, v);
+  return v;
+}
+// (max value, smallest index attaining it) over the segment: the reference's
+// strict-'<' first-argmax (GANet_kernel.cu:60-62, 122-123)
+template <int CTRL> GA_DEV void argmax_merge(float &v, int &k)
+{
+  const float ov = dpp_f<CTRL>(v, v);
+  const int ok = dpp_i<CTRL>(k, k);
+  const bool take = (ov > v) || (ov == v && ok < k);
+  v = take ? ov : v;
+  k = take ? ok : k;
+}
+template <int GD> GA_DEV void seg_argmax(float &v, int &k)
+{
+  if (GD >= 2) argmax_merge<DPP_QP_XOR1>(v, k);
+  if (GD >= 4) argmax_merge<DPP_QP_XOR2>(v, k);
+  if (GD >= 8) argmax_merge<DPP_ROW_HALF_MIRROR>(v, k);
+  if (GD >= 16) argmax_merge<DPP_ROW_MIRROR>(v, k);
+}
+
+// MI355X: workgroup b runs on XCD b % 8 (observed, speed only).  Give each XCD a
+// contiguous range of logical blocks so neighbouring tiles share one L2.
+GA_DEV int xcd_remap(int b, int nb)
+{
+  const int per = nb >> 3;
+  if (per == 0 || b >= (per << 3)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
+}  // namespace ga

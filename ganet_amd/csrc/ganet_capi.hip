@@ -1,0 +1,567 @@
+// ganet_capi.hip -- host side of libganet_hip.so: the C ABI declared in
+// include/ganet_hip.h, argument validation, kernel selection and launch.
+// Compiled by hipcc for gfx950 (product) and by g++ -DGA_HIPSIM (CPU test emulator).
+#include "ga_common.h"
+#include "lga_kernels.h"
+#include "misc_kernels.h"
+#include "sga_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "../../include/ganet_hip.h"
+
+#if defined(GA_HIPSIM)
+#define GA_LAUNCH(kern, grid, block, stream, ...) \
+  hipsim::launch((grid), (block), 0, [=]() { kern(__VA_ARGS__); })
+#define GA_EXPORT extern "C"
+#else
+#define GA_LAUNCH(kern, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+#define GA_EXPORT extern "C" __attribute__((visibility("default")))
+#endif
+
+namespace {
+
+using namespace ga;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char *what)
+{
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(GANET_E_RUNTIME, "%s: %s", what, hipGetErrorString(e));
+  return GANET_OK;
+}
+
+#define GA_TRY(expr)                         \
+  do {                                       \
+    const int rc_ = (expr);                  \
+    if (rc_ != GANET_OK) return rc_;         \
+  } while (0)
+
+#define GA_HIP(expr)                                                                   \
+  do {                                                                                 \
+    const hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return fail(GANET_E_RUNTIME, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- options ------------------------------------------------------------------
+struct Options {
+  int gd = 16;
+  int streams = 1;
+  int block_v = 256;
+  int block_h = 64;
+};
+Options g_opt;
+std::once_flag g_opt_once;
+
+void load_env_options()
+{
+  auto geti = [](const char *name, int &dst) {
+    const char *v = getenv(name);
+    if (v && *v) dst = atoi(v);
+  };
+  geti("GANET_SGA_GD", g_opt.gd);
+  geti("GANET_SGA_STREAMS", g_opt.streams);
+  geti("GANET_SGA_BLOCK_V", g_opt.block_v);
+  geti("GANET_SGA_BLOCK_H", g_opt.block_h);
+}
+const Options &opts()
+{
+  std::call_once(g_opt_once, load_env_options);
+  return g_opt;
+}
+
+// ---- side streams: one per extra aggregation direction, per device ------------------
+struct SidePool {
+  bool ready = false;
+  hipStream_t s[3];
+  hipEvent_t fork, join[3];
+};
+SidePool g_pool[16];
+std::mutex g_pool_mu;
+
+int get_pool(SidePool **out)
+{
+  int dev = 0;
+  GA_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return fail(GANET_E_RUNTIME, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  SidePool &p = g_pool[dev];
+  if (!p.ready) {
+    for (int i = 0; i < 3; i++) {
+      GA_HIP(hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking));
+      GA_HIP(hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming));
+    }
+    GA_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+    p.ready = true;
+  }
+  *out = &p;
+  return GANET_OK;
+}
+
+// ---- SGA kernel selection -----------------------------------------------------------
+// (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
+#define GA_SGA_PAIRS(X) \
+  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 9) X(4, 17)
+
+constexpr int fwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
+constexpr int fwd_nv(int dpl) { return dpl <= 5 ? 2 : 1; }
+constexpr int bwd_sb(int dpl) { return dpl <= 3 ? 4 : dpl <= 5 ? 2 : 1; }
+constexpr int bwd_nv(int) { return 1; }
+// float4 backward keeps 2 x (4 float4 + mask) per owned disparity in VGPRs: beyond
+// DPL = 5 it spills, so wider lanes use the element-strided traversal instead.
+constexpr bool bwd_rowvec_ok(int dpl) { return dpl <= 5; }
+
+bool pick_pair(int D, int want_gd, int *gd, int *dpl)
+{
+  int best_gd = 0, best_dpl = 0;
+#define X(G, P)                                                                    \
+  if ((G) == want_gd && (G) * (P) >= D && (best_gd == 0 || (P) < best_dpl)) {      \
+    best_gd = (G);                                                                 \
+    best_dpl = (P);                                                                \
+  }
+  GA_SGA_PAIRS(X)
+#undef X
+  if (best_gd == 0 && want_gd != 16) return pick_pair(D, 16, gd, dpl);
+  if (best_gd == 0) return false;
+  *gd = best_gd;
+  *dpl = best_dpl;
+  return true;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+ScanGeom make_geom(int S, int D, int H, int W, int dir, bool backward)
+{
+  ScanGeom g;
+  g.D = D; g.H = H; g.W = W;
+  g.HW = (i64)H * W;
+  const bool vertical = dir < 2;
+  g.L = vertical ? H : W;
+  g.Q = vertical ? W : H;
+  g.total_lines = S * g.Q;
+  g.line_stride = vertical ? 1 : W;
+  const i64 unit = vertical ? W : 1;
+  // forward visit order: down/right ascending, up/left descending; backward reverses it
+  const bool ascending = ((dir == 0 || dir == 2) != backward);
+  g.step_stride = ascending ? unit : -unit;
+  g.start = ascending ? 0 : (i64)(g.L - 1) * unit;
+  return g;
+}
+
+template <int GD, int DPL>
+int launch_scan_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir,
+                    hipStream_t st)
+{
+  const Options &o = opts();
+  ScanGeom geo = make_geom(S, D, H, W, dir, false);
+  const bool rowvec = dir >= 2 && (W % 4 == 0) && aligned16(x) && aligned16(g) && aligned16(A);
+  int block = dir < 2 ? o.block_v : o.block_h;
+  if (block < 64 || block > 256 || block % 64) block = 64;
+  const int lpb = block / GD;
+  const int grid = (geo.total_lines + lpb - 1) / lpb;
+  if (rowvec) {
+    GA_LAUNCH((sga_fwd_rowvec<GD, DPL, fwd_nv(DPL)>), dim3(grid), dim3(block), st, x, g, A, geo,
+              dir == 3 ? 1 : 0);
+  } else {
+    GA_LAUNCH((sga_fwd_strided<GD, DPL, fwd_sb(DPL)>), dim3(grid), dim3(block), st, x, g, A, geo);
+  }
+  return check_launch("sga scan forward");
+}
+
+template <int GD, int DPL>
+int launch_scan_bwd(const float *x, const float *g, const float *A, const uint8_t *mask,
+                    const float *gout, float *gx, float *gw, int S, int D, int H, int W, int dir,
+                    int accumulate, hipStream_t st)
+{
+  const Options &o = opts();
+  ScanGeom geo = make_geom(S, D, H, W, dir, true);
+  const bool rowvec = bwd_rowvec_ok(DPL) && dir >= 2 && (W % 4 == 0) && aligned16(x) &&
+                      aligned16(g) && aligned16(A) && aligned16(gout) && aligned16(gx) && aligned16(gw) && (((uintptr_t)mask & 3) == 0);
+  int block = dir < 2 ? o.block_v : o.block_h;
+  if (block < 64 || block > 256 || block % 64) block = 64;
+  const int lpb = block / GD;
+  const int grid = (geo.total_lines + lpb - 1) / lpb;
+  if (rowvec) {
+    // backward of `right` (2) visits w descending, of `left` (3) ascending
+    if constexpr (bwd_rowvec_ok(DPL))
+      GA_LAUNCH((sga_bwd_rowvec<GD, DPL, bwd_nv(DPL)>), dim3(grid), dim3(block), st, x, g, A, mask,
+                gout, gx, gw, geo, dir, accumulate, dir == 2 ? 1 : 0);
+  } else {
+    GA_LAUNCH((sga_bwd_strided<GD, DPL, bwd_sb(DPL)>), dim3(grid), dim3(block), st, x, g, A, mask,
+              gout, gx, gw, geo, dir, accumulate);
+  }
+  return check_launch("sga scan backward");
+}
+
+int check_dims5(const char *who, int N, int C, int D, int H, int W)
+{
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "%s: non-positive size N=%d C=%d D=%d H=%d W=%d", who, N, C, D, H, W);
+  if ((i64)D * H * W > 0x7fffffffLL / 4 || (i64)N * C * H > 0x7fffffffLL || (i64)N * C * W > 0x7fffffffLL)
+    return fail(GANET_E_UNSUPPORTED, "%s: slice too large for 32-bit line indexing", who);
+  return GANET_OK;
+}
+
+int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
+             hipStream_t st)
+{
+  int gd, dpl;
+  if (!pick_pair(D, opts().gd, &gd, &dpl))
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+#define X(G, P) \
+  if (gd == (G) && dpl == (P)) return launch_scan_fwd<G, P>(x, g, A, N * C, D, H, W, dir, st);
+  GA_SGA_PAIRS(X)
+#undef X
+  return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for GD=%d DPL=%d", gd, dpl);
+}
+
+int scan_bwd(const float *x, const float *g, const float *A, const uint8_t *mask, const float *gout,
+             float *gx, float *gw, int N, int C, int D, int H, int W, int dir, int accumulate,
+             hipStream_t st)
+{
+  int gd, dpl;
+  if (!pick_pair(D, opts().gd, &gd, &dpl))
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+#define X(G, P)                  \
+  if (gd == (G) && dpl == (P))   \
+    return launch_scan_bwd<G, P>(x, g, A, mask, gout, gx, gw, N * C, D, H, W, dir, accumulate, st);
+  GA_SGA_PAIRS(X)
+#undef X
+  return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for GD=%d DPL=%d", gd, dpl);
+}
+
+int ew_grid(i64 n)
+{
+  i64 g = (n + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- LGA dispatch -------------------------------------------------------------------
+template <int R>
+int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H, int W,
+                   bool transposed, hipStream_t st)
+{
+  LgaGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
+  if (transposed) GA_LAUNCH((lga_apply<R, true>), grid, dim3(256), st, x, f, y, geo);
+  else GA_LAUNCH((lga_apply<R, false>), grid, dim3(256), st, x, f, y, geo);
+  return check_launch("lga apply");
+}
+template <int R>
+int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc,
+                  hipStream_t st)
+{
+  LgaGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
+  GA_LAUNCH((lga_filter_grad<R>), grid, dim3(256), st, x, gy, gf, geo, acc);
+  return check_launch("lga filter grad");
+}
+
+int check_lga(const char *who, int B, int D, int H, int W, int radius)
+{
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "%s: non-positive size B=%d D=%d H=%d W=%d", who, B, D, H, W);
+  if (radius < 1 || radius > 3)
+    return fail(GANET_E_UNSUPPORTED, "%s: radius %d not in the compiled set {1,2,3}", who, radius);
+  if (B > 65535) return fail(GANET_E_UNSUPPORTED, "%s: batch %d > 65535 (grid.z)", who, B);
+  return GANET_OK;
+}
+
+__global__ void dpp_probe(int *out)
+{
+  const int lane = threadIdx.x;
+  out[0 * 64 + lane] = dpp_i<DPP_QP_XOR1>(-1, lane);
+  out[1 * 64 + lane] = dpp_i<DPP_QP_XOR2>(-1, lane);
+  out[2 * 64 + lane] = dpp_i<DPP_ROW_SHL1>(-1, lane);
+  out[3 * 64 + lane] = dpp_i<DPP_ROW_SHR1>(-1, lane);
+  out[4 * 64 + lane] = dpp_i<DPP_ROW_MIRROR>(-1, lane);
+  out[5 * 64 + lane] = dpp_i<DPP_ROW_HALF_MIRROR>(-1, lane);
+  float v = (float)((lane * 37) % 64);
+  int k = lane;
+  seg_argmax<16>(v, k);
+  out[6 * 64 + lane] = k;
+  out[7 * 64 + lane] = (int)seg_allsum<16>((float)lane);
+}
+
+}  // namespace
+
+// =====================================================================================
+GA_EXPORT int ganet_abi_version(void) { return GANET_ABI_VERSION; }
+GA_EXPORT const char *ganet_last_error(void) { return g_err; }
+GA_EXPORT int ganet_is_simulator(void)
+{
+#if defined(GA_HIPSIM)
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+GA_EXPORT int ganet_set_option(const char *name, int value)
+{
+  opts();
+  if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
+  if (!strcmp(name, "GANET_SGA_GD")) {
+    if (value != 4 && value != 8 && value != 16) return fail(GANET_E_INVALID, "GANET_SGA_GD must be 4, 8 or 16");
+    g_opt.gd = value;
+  } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
+  else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
+  else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
+  return GANET_OK;
+}
+
+GA_EXPORT int ganet_sga_scan_forward(const float *x, const float *g, float *A, int N, int C, int D,
+                                     int H, int W, int dir, void *stream)
+{
+  if (!x || !g || !A) return fail(GANET_E_INVALID, "ganet_sga_scan_forward: null pointer");
+  if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_scan_forward: dir %d", dir);
+  GA_TRY(check_dims5("ganet_sga_scan_forward", N, C, D, H, W));
+  return scan_fwd(x, g, A, N, C, D, H, W, dir, (hipStream_t)stream);
+}
+
+GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
+                                const float *g3, float *A_ws, float *out, uint8_t *mask, int N,
+                                int C, int D, int H, int W, void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out || !mask)
+    return fail(GANET_E_INVALID, "ganet_sga_forward: null pointer");
+  GA_TRY(check_dims5("ganet_sga_forward", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const float *gs[4] = {g0, g1, g2, g3};
+  if (opts().streams) {
+    SidePool *p;
+    GA_TRY(get_pool(&p));
+    GA_HIP(hipEventRecord(p->fork, st));
+    GA_TRY(scan_fwd(x, gs[0], A_ws, N, C, D, H, W, 0, st));
+    for (int d = 1; d < 4; d++) {
+      GA_HIP(hipStreamWaitEvent(p->s[d - 1], p->fork, 0));
+      GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, p->s[d - 1]));
+      GA_HIP(hipEventRecord(p->join[d - 1], p->s[d - 1]));
+      GA_HIP(hipStreamWaitEvent(st, p->join[d - 1], 0));
+    }
+  } else {
+    for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
+  }
+  GA_LAUNCH((sga_merge4<uint8_t>), dim3(ew_grid(n)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
+            A_ws + 3 * n, out, mask, n);
+  return check_launch("sga merge");
+}
+
+GA_EXPORT int ganet_sga_backward_dir(const float *x, const float *g, const float *A,
+                                     const uint8_t *mask, const float *grad_out, float *grad_x,
+                                     float *gw, int N, int C, int D, int H, int W, int dir,
+                                     int accumulate, void *stream)
+{
+  if (!x || !g || !A || !mask || !grad_out || !grad_x || !gw)
+    return fail(GANET_E_INVALID, "ganet_sga_backward_dir: null pointer");
+  if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_backward_dir: dir %d", dir);
+  GA_TRY(check_dims5("ganet_sga_backward_dir", N, C, D, H, W));
+  return scan_bwd(x, g, A, mask, grad_out, grad_x, gw, N, C, D, H, W, dir, accumulate ? 1 : 0,
+                  (hipStream_t)stream);
+}
+
+GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
+                                 const float *g3, const float *A_ws, const uint8_t *mask,
+                                 const float *grad_out, float *grad_x, float *gw0, float *gw1,
+                                 float *gw2, float *gw3, int N, int C, int D, int H, int W,
+                                 void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !mask || !grad_out || !grad_x || !gw0 || !gw1 ||
+      !gw2 || !gw3)
+    return fail(GANET_E_INVALID, "ganet_sga_backward: null pointer");
+  GA_TRY(check_dims5("ganet_sga_backward", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  const float *gs[4] = {g0, g1, g2, g3};
+  float *gws[4] = {gw0, gw1, gw2, gw3};
+  // grad_x is produced by direction 0 and accumulated by 1..3 on one stream (ordered)
+  for (int d = 0; d < 4; d++)
+    GA_TRY(scan_bwd(x, gs[d], A_ws + d * n, mask, grad_out, grad_x, gws[d], N, C, D, H, W, d,
+                    d > 0, (hipStream_t)stream));
+  return GANET_OK;
+}
+
+GA_EXPORT int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1,
+                                       const float *g2, const float *g3, float *temp_out,
+                                       float *out, float *mask_f32, int N, int C, int D, int H,
+                                       int W, void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !temp_out || !out || !mask_f32)
+    return fail(GANET_E_INVALID, "ganet_sga_forward_compat: null pointer");
+  GA_TRY(check_dims5("ganet_sga_forward_compat", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const float *gs[4] = {g0, g1, g2, g3};
+  GA_TRY(scan_fwd(x, gs[0], out, N, C, D, H, W, 0, st));
+  for (int d = 1; d < 4; d++) {
+    GA_TRY(scan_fwd(x, gs[d], temp_out, N, C, D, H, W, d, st));
+    GA_LAUNCH((sga_merge_running<float>), dim3(ew_grid(n)), dim3(256), st, temp_out, out, mask_f32,
+              n, d, d == 1 ? 1 : 0);
+    GA_TRY(check_launch("sga merge (compat)"));
+  }
+  return GANET_OK;
+}
+
+GA_EXPORT int ganet_sga_backward_compat(const float *x, const float *g0, const float *g1,
+                                        const float *g2, const float *g3, float *temp_out,
+                                        const float *mask_f32, float *max_idx,
+                                        const float *grad_out, float *temp_grad, float *grad_x,
+                                        float *gw0, float *gw1, float *gw2, float *gw3, int N,
+                                        int C, int D, int H, int W, void *stream)
+{
+  (void)max_idx;
+  if (!x || !g0 || !g1 || !g2 || !g3 || !temp_out || !mask_f32 || !grad_out || !temp_grad ||
+      !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
+    return fail(GANET_E_INVALID, "ganet_sga_backward_compat: null pointer");
+  GA_TRY(check_dims5("ganet_sga_backward_compat", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t *mask8 = reinterpret_cast<uint8_t *>(temp_grad);   // scratch: n bytes of 4n
+  GA_LAUNCH(mask_f32_to_u8, dim3(ew_grid(n)), dim3(256), st, mask_f32, mask8, n);
+  GA_TRY(check_launch("mask convert"));
+  const float *gs[4] = {g0, g1, g2, g3};
+  float *gws[4] = {gw0, gw1, gw2, gw3};
+  const int order[4] = {3, 0, 1, 2};   // GANet_kernel.cu:1040-1128
+  for (int i = 0; i < 4; i++) {
+    const int d = order[i];
+    if (d != 3) GA_TRY(scan_fwd(x, gs[d], temp_out, N, C, D, H, W, d, st));
+    GA_TRY(scan_bwd(x, gs[d], temp_out, mask8, grad_out, grad_x, gws[d], N, C, D, H, W, d, 1, st));
+  }
+  return GANET_OK;
+}
+
+GA_EXPORT int ganet_lga_forward(const float *x, const float *f, float *y, int B, int D, int H,
+                                int W, int radius, void *stream)
+{
+  if (!x || !f || !y) return fail(GANET_E_INVALID, "ganet_lga_forward: null pointer");
+  if (x == y) return fail(GANET_E_INVALID, "ganet_lga_forward: y must not alias x");
+  GA_TRY(check_lga("ganet_lga_forward", B, D, H, W, radius));
+  hipStream_t st = (hipStream_t)stream;
+  if (radius == 1) return launch_lga_fwd<1>(x, f, y, B, D, H, W, false, st);
+  if (radius == 2) return launch_lga_fwd<2>(x, f, y, B, D, H, W, false, st);
+  return launch_lga_fwd<3>(x, f, y, B, D, H, W, false, st);
+}
+
+GA_EXPORT int ganet_lga_backward(const float *x, const float *f, const float *gy, float *gx,
+                                 float *gf, int B, int D, int H, int W, int radius,
+                                 int accumulate_gf, void *stream)
+{
+  if (!x || !f || !gy || !gx || !gf) return fail(GANET_E_INVALID, "ganet_lga_backward: null pointer");
+  if (gx == gy) return fail(GANET_E_INVALID, "ganet_lga_backward: gx must not alias gy");
+  GA_TRY(check_lga("ganet_lga_backward", B, D, H, W, radius));
+  hipStream_t st = (hipStream_t)stream;
+  const int acc = accumulate_gf ? 1 : 0;
+  // filter gradient first: it is the only consumer of x, so gx may alias x afterwards
+  // (the reference's chained LGA2/LGA3 backward relies on that, functions/GANet.py:197).
+  if (radius == 1) { GA_TRY(launch_lga_gf<1>(x, gy, gf, B, D, H, W, acc, st)); return launch_lga_fwd<1>(gy, f, gx, B, D, H, W, true, st); }
+  if (radius == 2) { GA_TRY(launch_lga_gf<2>(x, gy, gf, B, D, H, W, acc, st)); return launch_lga_fwd<2>(gy, f, gx, B, D, H, W, true, st); }
+  GA_TRY(launch_lga_gf<3>(x, gy, gf, B, D, H, W, acc, st));
+  return launch_lga_fwd<3>(gy, f, gx, B, D, H, W, true, st);
+}
+
+GA_EXPORT int ganet_cost_volume_forward(const float *x, const float *y, float *cost, int N, int C,
+                                        int Dn, int H, int W, void *stream)
+{
+  if (!x || !y || !cost) return fail(GANET_E_INVALID, "ganet_cost_volume_forward: null pointer");
+  if (N <= 0 || C <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_cost_volume_forward: non-positive size");
+  const i64 n = (i64)N * 2 * C * Dn * H * W;
+  GA_LAUNCH(cost_volume_fwd, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, x, y, cost, N, C, Dn, H, W);
+  return check_launch("cost volume forward");
+}
+
+GA_EXPORT int ganet_cost_volume_backward(const float *grad_cost, float *grad_x, float *grad_y,
+                                         int N, int C, int Dn, int H, int W, void *stream)
+{
+  if (!grad_cost || !grad_x || !grad_y)
+    return fail(GANET_E_INVALID, "ganet_cost_volume_backward: null pointer");
+  if (N <= 0 || C <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_cost_volume_backward: non-positive size");
+  const i64 n = (i64)N * C * H * W;
+  GA_LAUNCH(cost_volume_bwd, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, grad_cost, grad_x, grad_y, N, C, Dn, H, W);
+  return check_launch("cost volume backward");
+}
+
+GA_EXPORT int ganet_disparity_regression_forward(const float *x, float *out, int N, int Dn, int H,
+                                                 int W, void *stream)
+{
+  if (!x || !out) return fail(GANET_E_INVALID, "ganet_disparity_regression_forward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_disparity_regression_forward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(disp_regression_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, out, N, Dn, HW);
+  return check_launch("disparity regression forward");
+}
+
+GA_EXPORT int ganet_disparity_regression_backward(const float *grad_out, float *grad_x, int N,
+                                                  int Dn, int H, int W, void *stream)
+{
+  if (!grad_out || !grad_x)
+    return fail(GANET_E_INVALID, "ganet_disparity_regression_backward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_disparity_regression_backward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, grad_out, grad_x, N, Dn, HW);
+  return check_launch("disparity regression backward");
+}
+
+GA_EXPORT int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream)
+{
+  if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GA_LAUNCH(dpp_probe, dim3(1), dim3(64), st, scratch_dev);
+  GA_TRY(check_launch("dpp probe"));
+#if defined(GA_HIPSIM)
+  memcpy(host_out, scratch_dev, sizeof(int) * 8 * 64);
+#else
+  GA_HIP(hipMemcpyAsync(host_out, scratch_dev, sizeof(int) * 8 * 64, hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+#endif
+  int bad = 0, first_pat = -1, first_lane = -1;
+  for (int lane = 0; lane < 64; lane++) {
+    const int r = lane & 15, row = lane & ~15;
+    int expect[8];
+    expect[0] = lane ^ 1;
+    expect[1] = lane ^ 2;
+    expect[2] = r < 15 ? lane + 1 : -1;
+    expect[3] = r > 0 ? lane - 1 : -1;
+    expect[4] = row + 15 - r;
+    expect[5] = (lane & ~7) + 7 - (lane & 7);
+    // argmax of (lane*37)%64 over the 16-lane row, smallest lane on ties
+    int bk = row;
+    for (int l = row; l < row + 16; l++)
+      if ((l * 37) % 64 > (bk * 37) % 64) bk = l;
+    expect[6] = bk;
+    expect[7] = 16 * row + 120;
+    for (int p = 0; p < 8; p++)
+      if (host_out[p * 64 + lane] != expect[p]) {
+        if (!bad) { first_pat = p; first_lane = lane; }
+        bad++;
+      }
+  }
+  if (bad)
+    return fail(GANET_E_RUNTIME, "DPP self-test: %d mismatches, first at pattern %d lane %d (got %d)",
+                bad, first_pat, first_lane, host_out[first_pat * 64 + first_lane]);
+  return GANET_OK;
+}

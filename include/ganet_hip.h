@@ -1,0 +1,151 @@
+/*
+ * ganet_hip.h -- C ABI of libganet_hip.so: GA-Net's guided-aggregation hot path
+ * (SGA, LGA, GetCostVolume, DisparityRegression) as hand-written HIP kernels for
+ * AMD Instinct MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary for the reference's native layer: every entry
+ * point below names the reference interface it replaces (paths relative to the
+ * reference repository root).  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers to contiguous fp32 (or uint8 where stated)
+ *     buffers owned by the caller; the library never allocates tensor storage.
+ *   - Volumes are [N,C,D,H,W]; guidance [N,C,5,H,W] (taps w0..w4, L1-normalised by
+ *     the caller as in models/GANet_deep.py:264-268); LGA input [B,D,H,W] with
+ *     filters [B,3*(2r+1)^2,H,W] (B = N for the 4-D ops, N*C for the "3d" ops).
+ *   - dir: 0 down, 1 up, 2 right, 3 left (the reference's mask values,
+ *     libs/GANet/src/GANet_kernel.cu:964-994).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *     Work is enqueued asynchronously; nothing here synchronises the device.
+ *   - Return value: 0 on success, negative on error (GANET_E_*); a message is
+ *     available from ganet_last_error() (thread-local).  The reference returns 1
+ *     unconditionally and never checks the runtime (GANet_cuda.cpp:5-64).
+ */
+#ifndef GANET_HIP_H
+#define GANET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GANET_OK 0
+#define GANET_E_INVALID (-1)      /* null pointer, non-positive size, bad dir      */
+#define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
+#define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
+
+#define GANET_ABI_VERSION 1
+int ganet_abi_version(void);
+const char *ganet_last_error(void);
+/* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
+int ganet_is_simulator(void);
+
+/* ---------------------------------------------------------------- SGA ------------ */
+
+/* One directional volume A_dir = scan_dir(x, g).
+ * Replaces: memcpy + sga_{down,up,right,left}_forward<<<>>>
+ *           (libs/GANet/src/GANet_kernel.cu:66-127, 285-346, 507-565, 720-778). */
+int ganet_sga_scan_forward(const float *x, const float *g, float *A,
+                           int N, int C, int D, int H, int W, int dir, void *stream);
+
+/* Fast-path forward used by ganet_amd's SgaFunction: the four directional volumes
+ * are written to A_ws ([4][N*C*D*H*W] floats, caller-allocated; kept for backward),
+ * out = element-wise max in reference order, mask = winning direction (uint8).
+ * Replaces: sga_kernel_forward (GANet_kernel.cu:935-998) incl. the three `Max`
+ * launches (:23-36) and five device memcpys. */
+int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
+                      const float *g3, float *A_ws, float *out, uint8_t *mask,
+                      int N, int C, int D, int H, int W, void *stream);
+
+/* One direction of the backward pass, single sweep: masked gather of gradOutput,
+ * first-argmax routing, reverse-scan adjoint, all five guidance-weight reductions.
+ * gradX: written (accumulate = 0) or accumulated into (accumulate = 1); gw
+ * ([N,C,5,H,W]) is written.
+ * Replaces: cudaMemset + get_temp_grad (:38-48) + MaxDepth (:50-64) +
+ *           sga_*_data_backward (:129-208 & mirrors) + sga_*_weight_backward
+ *           (:210-281 & mirrors). */
+int ganet_sga_backward_dir(const float *x, const float *g, const float *A, const uint8_t *mask,
+                           const float *grad_out, float *grad_x, float *gw,
+                           int N, int C, int D, int H, int W, int dir, int accumulate,
+                           void *stream);
+
+/* Fast-path backward: all four directions from the volumes saved by
+ * ganet_sga_forward.  grad_x and gw0..gw3 are fully overwritten.
+ * Replaces: sga_kernel_backward (GANet_kernel.cu:1000-1129). */
+int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
+                       const float *g3, const float *A_ws, const uint8_t *mask,
+                       const float *grad_out, float *grad_x, float *gw0, float *gw1,
+                       float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
+
+/* Reference-compatible buffer contract, for callers that keep the reference's
+ * libs/GANet/functions/GANet.py unchanged:
+ *   sga_cuda_forward(input, g0..g3, temp_out, output, mask)      GANet_cuda.cpp:39-48
+ *   sga_cuda_backward(input, g0..g3, temp_out, mask, max_idx, gradOutput, temp_grad,
+ *                     gradInput, grad0..grad3)                    GANet_cuda.cpp:50-64
+ * mask is float-valued; temp_out ends the forward holding A_left and is reused as
+ * scratch by the backward (which recomputes the other three volumes); temp_grad is
+ * scratch; gradInput / grad0..3 are ACCUMULATED into (the caller zero-fills them,
+ * functions/GANet.py:33-37); max_idx is left untouched (scratch in the reference). */
+int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1, const float *g2,
+                             const float *g3, float *temp_out, float *out, float *mask_f32,
+                             int N, int C, int D, int H, int W, void *stream);
+int ganet_sga_backward_compat(const float *x, const float *g0, const float *g1, const float *g2,
+                              const float *g3, float *temp_out, const float *mask_f32,
+                              float *max_idx, const float *grad_out, float *temp_grad,
+                              float *grad_x, float *gw0, float *gw1, float *gw2, float *gw3,
+                              int N, int C, int D, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------- LGA ------------ */
+
+/* One LGA pass, y fully overwritten.  radius in {1,2,3}.
+ * Replaces: lga_cuda_forward / lga3d_cuda_forward (GANet_cuda.cpp:14-37) ->
+ *           lga_filtering_forward (GANet_kernel.cu:1131-1175).  The reference
+ *           accumulates into a zero-filled output; here the zero-fill is not needed. */
+int ganet_lga_forward(const float *x, const float *f, float *y,
+                      int B, int D, int H, int W, int radius, void *stream);
+
+/* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
+ * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,
+ * functions/GANet.py:197-199).  gx must not alias x or gy.
+ * Replaces: lga_cuda_backward / lga3d_cuda_backward (GANet_cuda.cpp:5-28) ->
+ *           lga_filter_backward (:1177-1216) + cudaMemset + lga_data_backward
+ *           (:1218-1269). */
+int ganet_lga_backward(const float *x, const float *f, const float *gy, float *gx, float *gf,
+                       int B, int D, int H, int W, int radius, int accumulate_gf, void *stream);
+
+/* ------------------------------------------- GetCostVolume / DisparityRegression -- */
+
+/* cost [N,2C,Dn,H,W] from x,y [N,C,H,W]; Dn = maxdisp + 1.
+ * Replaces: GetCostVolume.forward (libs/GANet/modules/GANet.py:119-134) and its
+ * autograd-derived backward. */
+int ganet_cost_volume_forward(const float *x, const float *y, float *cost,
+                              int N, int C, int Dn, int H, int W, void *stream);
+int ganet_cost_volume_backward(const float *grad_cost, float *grad_x, float *grad_y,
+                               int N, int C, int Dn, int H, int W, void *stream);
+
+/* out [N,H,W] = sum_d d * x[N,Dn,H,W].
+ * Replaces: DisparityRegression.forward (libs/GANet/modules/GANet.py:142-148). */
+int ganet_disparity_regression_forward(const float *x, float *out,
+                                       int N, int Dn, int H, int W, void *stream);
+int ganet_disparity_regression_backward(const float *grad_out, float *grad_x,
+                                        int N, int Dn, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------- diagnostics ---- */
+
+/* Runs a 64-lane probe of every DPP pattern the kernels rely on and compares with
+ * the documented lane maps.  scratch: device buffer of >= 8*64 ints.  host_out
+ * (host memory, >= 8*64 ints) receives the raw lane values.  Synchronises `stream`.
+ * Returns 0 if all patterns match. */
+int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
+
+/* Tuning knobs (also read from the environment at first use):
+ *   GANET_SGA_GD=4|8|16   lanes per scanline            (default 16)
+ *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 1)
+ *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans */
+int ganet_set_option(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANET_HIP_H */

@@ -1,0 +1,178 @@
+// hipsim.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A minimal lockstep emulator that lets the HIP kernel sources under
+// ganet_amd/csrc/ compile with g++ and run on the CPU, so the CPU test-suite
+// (pytest -m "not gpu") can check kernel LOGIC -- indexing, DPP lane patterns,
+// segment reductions, LDS tiling, barriers -- against the oracle in a container
+// that has no GPU.  It is not a product path: ganet_amd never loads the library
+// built from it unless a test injects it explicitly (tests/sim_util.py).
+//
+// Model: one workgroup at a time; every HIP thread is a ucontext fiber on one OS
+// thread; __syncthreads() and the DPP exchange are generation barriers that yield
+// to a round-robin scheduler.  Wavefront = 64 consecutive threads.  DPP follows
+// the gfx9 ISA: quad_perm, row_shl/shr:n, row_mirror, row_half_mirror within
+// 16-lane rows; a lane whose source is out of range keeps `old`.
+#pragma once
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipMemcpyDeviceToDevice = 3, hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char *hipGetErrorString(hipError_t) { return "hipsim"; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+
+namespace hipsim {
+
+struct Fiber {
+  ucontext_t ctx;
+  char *stack = nullptr;
+  bool done = false;
+  dim3 tidx;
+};
+
+struct Barrier { int count = 0; int gen = 0; };
+
+struct State {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  int cur = 0;
+  int nthreads = 0;
+  dim3 blockDim_, gridDim_, blockIdx_;
+  Barrier block_bar;
+  std::vector<Barrier> wave_bar;
+  std::vector<int> xchg;
+  std::function<void()> body;
+  char *dyn_smem = nullptr;
+};
+
+inline State &S() { static State s; return s; }
+
+inline void yield() { State &s = S(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+
+inline void barrier_wait(Barrier &b, int n)
+{
+  const int gen = b.gen;
+  if (++b.count == n) { b.count = 0; b.gen++; }
+  else while (b.gen == gen) yield();
+}
+
+inline int flat_tid() { State &s = S(); const dim3 &t = s.fibers[s.cur].tidx; return t.x + s.blockDim_.x * (t.y + s.blockDim_.y * t.z); }
+inline int lane_id() { return flat_tid() & 63; }
+inline void syncthreads() { State &s = S(); barrier_wait(s.block_bar, s.nthreads); }
+
+inline int update_dpp(int old, int src, int ctrl)
+{
+  State &s = S();
+  const int tid = flat_tid(), wave = tid >> 6, lane = tid & 63;
+  const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
+  s.xchg[tid] = src;
+  barrier_wait(s.wave_bar[wave], wsize);
+  int sl = lane;
+  bool valid = true;
+  if (ctrl >= 0 && ctrl <= 0xFF) sl = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int r = (lane & 15) + (ctrl - 0x100); valid = r < 16; sl = (lane & ~15) + r; }
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int r = (lane & 15) - (ctrl - 0x110); valid = r >= 0; sl = (lane & ~15) + r; }
+  else if (ctrl == 0x140) sl = (lane & ~15) + (15 - (lane & 15));
+  else if (ctrl == 0x141) sl = (lane & ~7) + (7 - (lane & 7));
+  else { fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+  if (valid && sl >= wsize) valid = false;   // inactive source lane: dest keeps old
+  const int v = valid ? s.xchg[wave * 64 + sl] : old;
+  barrier_wait(s.wave_bar[wave], wsize);
+  return v;
+}
+
+inline void fiber_entry()
+{
+  State &s = S();
+  s.body();
+  s.fibers[s.cur].done = true;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body)
+{
+  State &s = S();
+  const int nt = (int)(block.x * block.y * block.z);
+  const size_t STACK = 256 * 1024;
+  s.nthreads = nt;
+  s.blockDim_ = block;
+  s.gridDim_ = grid;
+  s.body = body;
+  if ((int)s.fibers.size() < nt) {
+    const size_t old = s.fibers.size();
+    s.fibers.resize(nt);
+    for (size_t i = old; i < (size_t)nt; i++) s.fibers[i].stack = (char *)malloc(STACK);
+  }
+  s.wave_bar.assign((nt + 63) / 64, Barrier());
+  s.xchg.assign(nt, 0);
+  std::vector<char> smem(shmem + 64);
+  s.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        s.blockIdx_ = dim3(bx, by, bz);
+        s.block_bar = Barrier();
+        for (auto &w : s.wave_bar) w = Barrier();
+        for (int t = 0; t < nt; t++) {
+          Fiber &f = s.fibers[t];
+          f.done = false;
+          f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack;
+          f.ctx.uc_stack.ss_size = STACK;
+          f.ctx.uc_link = &s.sched;
+          makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        }
+        int remaining = nt;
+        long spins = 0;
+        while (remaining > 0) {
+          for (int t = 0; t < nt; t++) {
+            if (s.fibers[t].done) continue;
+            s.cur = t;
+            swapcontext(&s.sched, &s.fibers[t].ctx);
+            if (s.fibers[t].done) remaining--;
+          }
+          if (++spins > 100000000L) { fprintf(stderr, "hipsim: deadlock (divergent barrier/DPP?)\n"); abort(); }
+        }
+      }
+}
+
+}  // namespace hipsim
+
+#define threadIdx (hipsim::S().fibers[hipsim::S().cur].tidx)
+#define blockIdx (hipsim::S().blockIdx_)
+#define blockDim (hipsim::S().blockDim_)
+#define gridDim (hipsim::S().gridDim_)
+#define __syncthreads() hipsim::syncthreads()

@@ -1,0 +1,148 @@
+"""Parity checks shared by the CPU-emulator tests (numpy buffers, tests/hipsim) and the
+GPU tests (torch device buffers): every check drives the C ABI of include/ganet_hip.h
+and compares with the oracle / golden fixtures.  `dev` abstracts buffer handling."""
+import numpy as np
+
+TOL = 1e-4   # north_star: fp32 max-abs <= 1e-4 for SGA/LGA forward + backward
+
+
+def l1norm(g, axis):
+    return (g / np.abs(g).sum(axis, keepdims=True)).astype(np.float32)
+
+
+def sga_inputs(shape, seed):
+    rng = np.random.default_rng(seed)
+    N, C, D, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    gs = [l1norm(rng.standard_normal((N, C, 5, H, W)), 2) for _ in range(4)]
+    go = rng.standard_normal(shape).astype(np.float32)
+    return x, gs, go
+
+
+class NumpyDev:
+    """Host buffers for the emulator build."""
+    stream = None
+
+    def to(self, a):
+        return np.ascontiguousarray(a)
+
+    def empty(self, shape, dtype=np.float32):
+        return np.empty(shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        return np.zeros(shape, dtype)
+
+    def ptr(self, a):
+        return a.ctypes.data
+
+    def host(self, a):
+        return a
+
+    def sync(self):
+        pass
+
+
+def check_sga_scan(api, dev, oracle, x, g, direction):
+    N, C, D, H, W = x.shape
+    dx, dg = dev.to(x), dev.to(g)
+    A = dev.empty(x.shape)
+    api.call("ganet_sga_scan_forward", dev.ptr(dx), dev.ptr(dg), dev.ptr(A), N, C, D, H, W, direction, dev.stream)
+    dev.sync()
+    want = oracle.sga_scan(x, g, direction)
+    got = dev.host(A)
+    assert np.array_equal(got, want), f"dir {direction}: {int((got != want).sum())} of {got.size} differ, max {np.abs(got - want).max()}"
+
+
+def run_sga_forward(api, dev, x, gs):
+    N, C, D, H, W = x.shape
+    dx = dev.to(x)
+    dg = [dev.to(g) for g in gs]
+    A = dev.empty((4,) + x.shape)
+    out = dev.empty(x.shape)
+    mask = dev.empty(x.shape, np.uint8)
+    api.call("ganet_sga_forward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(out), dev.ptr(mask),
+             N, C, D, H, W, dev.stream)
+    dev.sync()
+    return dx, dg, A, out, mask
+
+
+def check_sga_forward_backward(api, dev, x, gs, go, want):
+    """want: dict(out, mask(uint8), gx, gw0..gw3, optional A0..A3) from the oracle/golden."""
+    N, C, D, H, W = x.shape
+    dx, dg, A, out, mask = run_sga_forward(api, dev, x, gs)
+    hA = dev.host(A)
+    for d in range(4):
+        if f"A{d}" in want:
+            assert np.array_equal(hA[d], want[f"A{d}"]), f"A{d}"
+    assert np.array_equal(dev.host(out), want["out"]), "out"
+    assert np.array_equal(dev.host(mask), want["mask"]), "direction mask must be bit-exact"
+    dgo = dev.to(go)
+    gx = dev.empty(x.shape)
+    gw = [dev.empty(gs[0].shape) for _ in range(4)]
+    api.call("ganet_sga_backward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(mask), dev.ptr(dgo),
+             dev.ptr(gx), *[dev.ptr(g) for g in gw], N, C, D, H, W, dev.stream)
+    dev.sync()
+    err = {"gx": float(np.abs(dev.host(gx) - want["gx"]).max())}
+    for d in range(4):
+        err[f"gw{d}"] = float(np.abs(dev.host(gw[d]) - want[f"gw{d}"]).max())
+    assert max(err.values()) <= TOL, err
+    return err
+
+
+def check_sga_compat(api, dev, x, gs, go, want):
+    """Reference buffer contract (sga_cuda_forward / sga_cuda_backward)."""
+    N, C, D, H, W = x.shape
+    dx = dev.to(x)
+    dg = [dev.to(g) for g in gs]
+    tmp, out, mask = dev.zeros(x.shape), dev.zeros(x.shape), dev.zeros(x.shape)
+    api.call("ganet_sga_forward_compat", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(tmp), dev.ptr(out),
+             dev.ptr(mask), N, C, D, H, W, dev.stream)
+    dev.sync()
+    assert np.array_equal(dev.host(out), want["out"])
+    assert np.array_equal(dev.host(mask).astype(np.uint8), want["mask"])
+    assert np.array_equal(dev.host(tmp), want["tmp"]), "temp_out must hold A_left"
+    dgo = dev.to(go)
+    gx = dev.zeros(x.shape)
+    gw = [dev.zeros(gs[0].shape) for _ in range(4)]
+    tgrad = dev.zeros(x.shape)
+    idx = dev.zeros((N, C, H, W))
+    api.call("ganet_sga_backward_compat", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(tmp), dev.ptr(mask),
+             dev.ptr(idx), dev.ptr(dgo), dev.ptr(tgrad), dev.ptr(gx), *[dev.ptr(g) for g in gw],
+             N, C, D, H, W, dev.stream)
+    dev.sync()
+    err = {"gx": float(np.abs(dev.host(gx) - want["gx"]).max())}
+    for d in range(4):
+        err[f"gw{d}"] = float(np.abs(dev.host(gw[d]) - want[f"gw{d}"]).max())
+    assert max(err.values()) <= TOL, err
+    return err
+
+
+def lga_dims(x):
+    if x.ndim == 5:
+        return x.shape[0] * x.shape[1], x.shape[2], x.shape[3], x.shape[4]
+    return x.shape
+
+
+def check_lga_chain(api, dev, x, f, gy, r, passes, want):
+    """Chained LGA passes (Lga/Lga2/Lga3 and the 3d forms) through the one-pass ABI."""
+    B, D, H, W = lga_dims(x)
+    df = dev.to(f)
+    ins = [dev.to(x)]
+    for _ in range(passes):
+        y = dev.empty(x.shape)
+        api.call("ganet_lga_forward", dev.ptr(ins[-1]), dev.ptr(df), dev.ptr(y), B, D, H, W, r, dev.stream)
+        ins.append(y)
+    dev.sync()
+    e_y = float(np.abs(dev.host(ins[-1]) - want["y"]).max())
+    g = dev.to(gy)
+    gf = dev.empty(f.shape)
+    for k, xin in enumerate(reversed(ins[:-1])):
+        gx = dev.empty(x.shape)
+        api.call("ganet_lga_backward", dev.ptr(xin), dev.ptr(df), dev.ptr(g), dev.ptr(gx), dev.ptr(gf),
+                 B, D, H, W, r, 1 if k > 0 else 0, dev.stream)
+        g = gx
+    dev.sync()
+    err = {"y": e_y, "gx": float(np.abs(dev.host(g) - want["gx"]).max()),
+           "gf": float(np.abs(dev.host(gf) - want["gf"]).max())}
+    assert max(err.values()) <= TOL, err
+    return err

@@ -1,0 +1,75 @@
+"""LGA / GetCostVolume / DisparityRegression kernel logic on the CPU emulator
+(tests/hipsim), through the C ABI, against golden fixtures and the oracle."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from golden_util import lga_case_names, load
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from sim_util import sim_api
+    return sim_api()
+
+
+DEV = pc.NumpyDev()
+
+
+@pytest.mark.parametrize("name", lga_case_names())
+def test_lga_chain_matches_golden(sim, name):
+    z = load("lga_golden.npz")
+    r, passes = (int(v) for v in z[f"{name}.meta"])
+    want = {"y": z[f"{name}.y"], "gx": z[f"{name}.gx"], "gf": z[f"{name}.gf"]}
+    err = pc.check_lga_chain(sim, DEV, z[f"{name}.x"], z[f"{name}.f"], z[f"{name}.gy"], r, passes, want)
+    assert max(err.values()) < 2e-5, err
+
+
+@pytest.mark.parametrize("shape,r", [((1, 9, 10, 34), 2), ((2, 5, 17, 33), 2), ((1, 4, 9, 40), 1),
+                                     ((1, 6, 3, 70), 3), ((1, 1, 8, 32), 2), ((1, 13, 16, 64), 2)])
+def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
+    """Shapes that cross tile borders (32x8 tiles) and LDS stage boundaries (4 planes)."""
+    rng = np.random.default_rng(sum(shape) + r)
+    fs = list(shape)
+    fs[1] = 3 * (2 * r + 1) ** 2
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal(fs), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y = port_oracle.lga_forward(x, f, r)
+    gx, gf = port_oracle.lga_backward(x, f, gy, r)
+    err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
+    assert max(err.values()) < 2e-5, err
+
+
+def test_cost_volume_and_regression(sim, port_oracle):
+    rng = np.random.default_rng(5)
+    N, C, H, W, maxdisp = 2, 3, 4, 11, 6
+    Dn = maxdisp + 1
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    cost = np.empty((N, 2 * C, Dn, H, W), np.float32)
+    sim.call("ganet_cost_volume_forward", x.ctypes.data, y.ctypes.data, cost.ctypes.data, N, C, Dn, H, W, None)
+    assert np.array_equal(cost, port_oracle.cost_volume(x, y, maxdisp))
+    # adjoint identity <cost(x,y), g> == <x, gx> + <y, gy>
+    g = rng.standard_normal(cost.shape).astype(np.float32)
+    gx, gy = np.empty_like(x), np.empty_like(y)
+    sim.call("ganet_cost_volume_backward", g.ctypes.data, gx.ctypes.data, gy.ctypes.data, N, C, Dn, H, W, None)
+    lhs = float((cost.astype(np.float64) * g).sum())
+    rhs = float((x.astype(np.float64) * gx).sum() + (y.astype(np.float64) * gy).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+    p = rng.random((N, Dn, H, W)).astype(np.float32)
+    out = np.empty((N, H, W), np.float32)
+    sim.call("ganet_disparity_regression_forward", p.ctypes.data, out.ctypes.data, N, Dn, H, W, None)
+    np.testing.assert_allclose(out, port_oracle.disparity_regression(p, maxdisp), atol=1e-5)
+    go = rng.standard_normal((N, H, W)).astype(np.float32)
+    gp = np.empty_like(p)
+    sim.call("ganet_disparity_regression_backward", go.ctypes.data, gp.ctypes.data, N, Dn, H, W, None)
+    want = go[:, None] * np.arange(Dn, dtype=np.float32)[None, :, None, None]
+    assert np.array_equal(gp, want)
+
+
+def test_lga_unsupported_radius(sim):
+    from ganet_amd._native import GanetError
+    x = np.zeros((1, 2, 2, 2), np.float32)
+    with pytest.raises(GanetError, match="radius"):
+        sim.call("ganet_lga_forward", x.ctypes.data, x.ctypes.data, x.ctypes.data + 4, 1, 2, 2, 2, 4, None)
