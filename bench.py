@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py -- cost-volumes/sec (SGA + LGA2 forward+backward) at 240x624x192 on MI355X.
+
+One STEP = one cost volume as GA-Net feeds the ops at crop 240x624, max_disp 192
+(SURVEY.md 8d):
+    SgaFunction  fwd+bwd on x [1,32,65,80,208] with four guidance tensors [1,32,5,80,208]
+  + Lga2Function fwd+bwd (radius 2, two chained passes) on x [1,193,240,624], f [1,75,240,624]
+fp32, synthetic inputs resident in HBM before the timed region, torch.manual_seed(123).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver as torch.distributed.run, one rank per GPU; ranks run independent
+cost volumes (the ops have no cross-sample term, so there is no data-path collective): weak
+scaling, value = N*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      HBM roofline of the dominant kernel family (largest share of the step), from
+                per-stage HIP-event timings taken on the launch stream after the timed region
+  cpu_baseline  the CPU checker (oracle/_ref = the reference's own kernel bodies when the prebuilt
+                .so is present, else the C restatement) timed on this box's host cores on ONE
+                cost volume of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from ganet_amd import dist as gdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SGA_SHAPE = (1, 32, 65, 80, 208)
+LGA_SHAPE = (1, 193, 240, 624)
+RADIUS = 2
+
+# algorithmic bytes (SURVEY.md 8d / BASELINE.md 2): inputs read once + outputs written once
+_V = 4 * 1 * 32 * 65 * 80 * 208
+_G = 4 * 1 * 32 * 5 * 80 * 208
+_VL = 4 * 1 * 193 * 240 * 624
+_F = 4 * 1 * 75 * 240 * 624
+ALG_BYTES = {
+    "sga_fwd": 2 * _V + 4 * _G,
+    "sga_bwd": 3 * _V + 8 * _G,
+    "lga2_fwd": 3 * _VL + _F,
+    "lga2_bwd": 4 * _VL + 2 * _F,
+}
+UNIT_BYTES = sum(ALG_BYTES.values())     # 1,764,106,240 B per cost volume
+
+
+def make_inputs(device):
+    torch.manual_seed(123)
+    x = torch.randn(SGA_SHAPE, device=device, requires_grad=True)
+    gshape = SGA_SHAPE[:2] + (5,) + SGA_SHAPE[3:]
+    gs = [F.normalize(torch.randn(gshape, device=device), p=1, dim=2).requires_grad_() for _ in range(4)]
+    go = torch.randn(SGA_SHAPE, device=device)
+    xl = torch.randn(LGA_SHAPE, device=device, requires_grad=True)
+    f = F.normalize(torch.randn((1, 75) + LGA_SHAPE[2:], device=device), p=1, dim=1).requires_grad_()
+    gy = torch.randn(LGA_SHAPE, device=device)
+    return x, gs, go, xl, f, gy
+
+
+def one_step(inp):
+    from ganet_amd.functions.GANet import Lga2Function, SgaFunction
+    x, gs, go, xl, f, gy = inp
+    out = SgaFunction.apply(x, *gs)
+    g1 = torch.autograd.grad(out, [x] + gs, go)
+    y = Lga2Function.apply(xl, f, RADIUS)
+    g2 = torch.autograd.grad(y, [xl, f], gy)
+    return g1, g2
+
+
+def stage_timings(inp, iters=5):
+    """Per-stage device time (ms) with HIP events on the launch stream, via the C ABI."""
+    from ganet_amd import _native
+    lib = _native.lib()
+    x, gs, go, xl, f, gy = [t.detach() if torch.is_tensor(t) else [u.detach() for u in t] for t in inp]
+    N, C, D, H, W = x.shape
+    n = x.numel()
+    st = torch.cuda.current_stream().cuda_stream
+    A = torch.empty((4,) + tuple(x.shape), device=x.device)
+    out = torch.empty_like(x)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    gx = torch.empty_like(x)
+    gw = [torch.empty_like(g) for g in gs]
+    B, DL, HL, WL = xl.shape
+    t1, y, gt1, gxl = (torch.empty_like(xl) for _ in range(4))
+    gf = torch.empty_like(f)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    res = {}
+    names = ["down", "up", "right", "left"]
+    for d in range(4):
+        res[f"sga_scan_fwd_{names[d]}"] = timed(lambda d=d: lib.call(
+            "ganet_sga_scan_forward", x.data_ptr(), gs[d].data_ptr(), A[d].data_ptr(), N, C, D, H, W, d, st))
+    res["sga_forward_fused_call"] = timed(lambda: lib.call(
+        "ganet_sga_forward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), out.data_ptr(),
+        mask.data_ptr(), N, C, D, H, W, st))
+    for d in range(4):
+        res[f"sga_bwd_{names[d]}"] = timed(lambda d=d: lib.call(
+            "ganet_sga_backward_dir", x.data_ptr(), gs[d].data_ptr(), A[d].data_ptr(), mask.data_ptr(),
+            go.data_ptr(), gx.data_ptr(), gw[d].data_ptr(), N, C, D, H, W, d, 1 if d else 0, st))
+    res["lga_fwd_pass"] = timed(lambda: lib.call(
+        "ganet_lga_forward", xl.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, RADIUS, st))
+    res["lga_bwd_pass"] = timed(lambda: lib.call(
+        "ganet_lga_backward", xl.data_ptr(), f.data_ptr(), gy.data_ptr(), gxl.data_ptr(), gf.data_ptr(),
+        B, DL, HL, WL, RADIUS, 0, st))
+    return res
+
+
+def roofline_from_stages(stages):
+    """Dominant kernel family = the one with the largest time share of a step.  `achieved` =
+    that family's algorithmic bytes (op-level figure of SURVEY 8d divided over its launches)
+    / its average launch duration."""
+    fam = {
+        "sga_scan_fwd": ([k for k in stages if k.startswith("sga_scan_fwd_")], ALG_BYTES["sga_fwd"] / 4),
+        "sga_scan_bwd": ([k for k in stages if k.startswith("sga_bwd_")], ALG_BYTES["sga_bwd"] / 4),
+        "lga_apply+filter_grad (bwd pass)": (["lga_bwd_pass"], ALG_BYTES["lga2_bwd"] / 2),
+        "lga_apply (fwd pass)": (["lga_fwd_pass"], ALG_BYTES["lga2_fwd"] / 2),
+    }
+    # launches per step: 4 scans fwd, 4 bwd, 2 lga fwd passes, 2 lga bwd passes
+    mult = {"sga_scan_fwd": 1, "sga_scan_bwd": 1, "lga_apply+filter_grad (bwd pass)": 2, "lga_apply (fwd pass)": 2}
+    best, best_t = None, -1.0
+    for name, (keys, _) in fam.items():
+        t = sum(stages[k] for k in keys) * mult[name]
+        if t > best_t:
+            best, best_t = name, t
+    keys, bytes_per_launch = fam[best]
+    avg_ms = sum(stages[k] for k in keys) / len(keys)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": best, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
+            "traffic": None}
+
+
+def cpu_baseline():
+    """One cost volume (SGA fwd+bwd + LGA2 fwd+bwd) on the host cores through the CPU checker."""
+    import numpy as np
+    from oracle import oracle
+    kind = "reference" if oracle.have("reference") else "port"
+    ora = oracle.Oracle(kind)
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal(SGA_SHAPE).astype(np.float32)
+    gshape = SGA_SHAPE[:2] + (5,) + SGA_SHAPE[3:]
+    gs = []
+    for _ in range(4):
+        g = rng.standard_normal(gshape).astype(np.float32)
+        gs.append((g / np.abs(g).sum(2, keepdims=True)).astype(np.float32))
+    go = rng.standard_normal(SGA_SHAPE).astype(np.float32)
+    xl = rng.standard_normal(LGA_SHAPE).astype(np.float32)
+    f = rng.standard_normal((1, 75) + LGA_SHAPE[2:]).astype(np.float32)
+    f = (f / np.abs(f).sum(1, keepdims=True)).astype(np.float32)
+    gy = rng.standard_normal(LGA_SHAPE).astype(np.float32)
+    t0 = time.time()
+    out, tmp, mask = ora.sga_forward(x, *gs)
+    ora.sga_backward(x, *gs, tmp, mask, go)
+    y, ins = ora.lga_chain_forward(xl, f, RADIUS, 2)
+    ora.lga_chain_backward(ins, f, gy, RADIUS)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "cost-volumes/sec", "cores": int(ora.threads), "kind": kind,
+            "sample": "1 cost volume (SGA fwd+bwd + LGA2 fwd+bwd, same shapes), %.1f s wall" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    ctx = gdist.init(args.gpus)
+    device = torch.device("cuda", ctx.local_rank)
+    torch.cuda.set_device(device)
+    from ganet_amd import _native
+    assert not _native.lib().is_simulator
+
+    inp = make_inputs(device)
+    for _ in range(args.warmup):
+        one_step(inp)
+    elapsed = gdist.timed_region(ctx, lambda: [one_step(inp) for _ in range(args.steps)],
+                                 sync=torch.cuda.synchronize)
+    value = ctx.world_size * args.steps / elapsed
+
+    line = {
+        "metric": "cost-volumes/sec (SGA+LGA fwd+bwd) at 240x624x192",
+        "value": round(value, 2), "unit": "cost-volumes/sec", "n_gpus": ctx.world_size,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: SGA fwd+bwd [1,32,65,80,208] (4x guidance [1,32,5,80,208]) + "
+                               "LGA2 r=2 fwd+bwd [1,193,240,624] (filters [1,75,240,624]), one sample per GPU",
+                   "parallelism": "independent cost volumes per GPU, no data-path collective"},
+        "unit_alg_bytes": UNIT_BYTES,
+        "unit_hbm_frac": round(value / ctx.world_size * UNIT_BYTES / (HBM_PEAK_GBS * 1e9), 4),
+    }
+    if ctx.rank == 0:
+        if not args.no_roofline:
+            stages = stage_timings(inp)
+            line["roofline"] = roofline_from_stages(stages)
+            line["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        if not args.no_cpu_baseline and ctx.world_size == 1:
+            line["cpu_baseline"] = cpu_baseline()
+    gdist.finish(ctx)
+    if ctx.rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""One-process-per-GPU plumbing for the benchmark and for data-parallel callers.
+
+The guided-aggregation ops have no cross-sample term (every index in the reference kernels is
+per-(n,c): GANet_kernel.cu:77-78, 1148-1152), so the hot path shards over the batch with NO
+data-path collective: each rank owns whole samples.  What is collective is only (a) the timing
+protocol of bench.py (barrier + max-over-ranks) and (b), for training callers, the parameter
+gradient all-reduce, for which `all_reduce_mean_` below is the bucketed RCCL form
+(backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests)."""
+import os
+import time
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistCtx:
+    rank: int
+    local_rank: int
+    world_size: int
+    initialized_here: bool
+
+
+def init(expected_world=None, backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); world 1 needs no group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if expected_world is not None and expected_world != world:
+        if world == 1 and expected_world > 1:
+            raise RuntimeError(f"--gpus {expected_world} needs a torch.distributed.run launch "
+                               f"(one rank per GPU); WORLD_SIZE is {world}")
+        raise RuntimeError(f"--gpus {expected_world} but WORLD_SIZE={world}")
+    started = False
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        started = True
+    return DistCtx(rank, local, world, started)
+
+
+def barrier(ctx):
+    if ctx.world_size > 1:
+        dist.barrier()
+
+
+def max_over_ranks(ctx, value, device=None):
+    if ctx.world_size == 1:
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", ctx.local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_region(ctx, fn, sync=lambda: None):
+    """barrier + device sync, run fn, device sync + barrier; returns the MAX wall time over ranks."""
+    barrier(ctx)
+    sync()
+    t0 = time.perf_counter()
+    fn()
+    sync()
+    local = time.perf_counter() - t0
+    barrier(ctx)
+    return max_over_ranks(ctx, local)
+
+
+def shard_range(n_items, ctx):
+    """Contiguous, near-equal split of n_items independent units (samples) over ranks."""
+    base, extra = divmod(n_items, ctx.world_size)
+    start = ctx.rank * base + min(ctx.rank, extra)
+    return start, start + base + (1 if ctx.rank < extra else 0)
+
+
+def all_reduce_mean_(tensors, ctx, bucket_bytes=64 << 20):
+    """In-place mean of gradient tensors across ranks, in flat buckets (few, large collectives:
+    xGMI rings are per-link bound, so bucket size -- not call count -- sets the rate)."""
+    if ctx.world_size == 1:
+        return
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(ctx.world_size)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        bucket, size = [], 0
+
+    for t in tensors:
+        bucket.append(t)
+        size += t.numel() * t.element_size()
+        if size >= bucket_bytes:
+            flush()
+    flush()
+
+
+def finish(ctx):
+    if ctx.initialized_here and dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,279 @@
+"""autograd.Functions with the names, argument order and return values of the reference's
+libs/GANet/functions/GANet.py, running on the gfx950 kernels of libganet_hip.so.
+
+Differences from the reference that are deliberate:
+  * outputs are allocated with torch.empty (the kernels write every element; the
+    reference needs zero-filled buffers because its kernels accumulate);
+  * the incoming gradOutput is never written (Lga2Function.backward in the reference
+    overwrites autograd's grad tensor in place, functions/GANet.py:197-200);
+  * launches go to torch's CURRENT stream of the tensor's device (the reference uses the
+    legacy default stream with blocking memcpys, GANet_kernel.cu:961-964);
+  * LgaFunction / Lga3Function work (broken in the reference: undefined `radius`,
+    typo `fitlers`); Lgf2Function, which calls a native symbol that does not exist in the
+    reference (lgf_cuda_*), is provided as an alias of Lga2Function;
+  * non-HIP tensors raise: there is no CPU implementation here, as in the reference.
+"""
+import os
+
+import torch
+from torch.autograd import Function
+
+from .. import _native
+
+__all__ = ["SgaFunction", "LgaFunction", "Lga2Function", "Lga3Function", "Lga3dFunction",
+           "Lga3d2Function", "Lga3d3Function", "Lgf2Function", "MyLossFunction", "MyLoss2Function",
+           "GetCostVolumeFunction", "DisparityRegressionFunction"]
+
+
+def _lib():
+    return _native.lib()
+
+
+def _check(*tensors):
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("ganet_amd ops need HIP (cuda) tensors: there is no CPU path")
+        if t.dtype != torch.float32:
+            raise TypeError(f"ganet_amd ops are fp32 only, got {t.dtype}")
+        if t.device != dev:
+            raise RuntimeError("all tensors of a ganet_amd op must live on one device")
+        assert t.is_contiguous(), "ganet_amd ops need contiguous tensors"   # functions/GANet.py:11
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+class SgaFunction(Function):
+    """SgaFunction.apply(input, g0, g1, g2, g3) -> output   (functions/GANet.py:8-48).
+
+    Saves the four directional volumes and a uint8 direction mask so that backward is one
+    sweep per direction (set GANET_SGA_SAVE=recompute for the reference's memory profile:
+    save A_left + float mask, recompute the other three volumes in backward)."""
+
+    @staticmethod
+    def forward(ctx, input, g0, g1, g2, g3):
+        _check(input, g0, g1, g2, g3)
+        if input.dim() != 5 or any(g.shape != (input.shape[0], input.shape[1], 5) + tuple(input.shape[3:])
+                                   for g in (g0, g1, g2, g3)):
+            raise ValueError("SGA expects input [N,C,D,H,W] and four guidance tensors [N,C,5,H,W]")
+        N, C, D, H, W = input.shape
+        ctx.recompute = os.environ.get("GANET_SGA_SAVE", "") == "recompute"
+        with torch.cuda.device_of(input):
+            output = torch.empty_like(input)
+            if ctx.recompute:
+                temp_out = torch.empty_like(input)
+                mask = torch.empty_like(input)
+                _lib().call("ganet_sga_forward_compat", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(temp_out),
+                            _p(output), _p(mask), N, C, D, H, W, _stream())
+                ctx.save_for_backward(input, g0, g1, g2, g3, temp_out, mask)
+            else:
+                A = torch.empty((4,) + tuple(input.shape), dtype=input.dtype, device=input.device)
+                mask = torch.empty(input.shape, dtype=torch.uint8, device=input.device)
+                _lib().call("ganet_sga_forward", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(A), _p(output),
+                            _p(mask), N, C, D, H, W, _stream())
+                ctx.save_for_backward(input, g0, g1, g2, g3, A, mask)
+        return output
+
+    @staticmethod
+    def backward(ctx, gradOutput):
+        input, g0, g1, g2, g3, saved, mask = ctx.saved_tensors
+        gradOutput = gradOutput.contiguous()
+        _check(gradOutput)
+        N, C, D, H, W = input.shape
+        with torch.cuda.device_of(gradOutput):
+            if ctx.recompute:
+                gradInput = torch.zeros_like(input)
+                grads = [torch.zeros_like(g) for g in (g0, g1, g2, g3)]
+                temp_out = saved.clone()          # backward reuses it as scratch; keep ctx re-entrant
+                temp_grad = torch.empty_like(input)
+                max_idx = torch.empty((N, C, H, W), dtype=input.dtype, device=input.device)
+                _lib().call("ganet_sga_backward_compat", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(temp_out),
+                            _p(mask), _p(max_idx), _p(gradOutput), _p(temp_grad), _p(gradInput),
+                            *[_p(g) for g in grads], N, C, D, H, W, _stream())
+            else:
+                gradInput = torch.empty_like(input)
+                grads = [torch.empty_like(g) for g in (g0, g1, g2, g3)]
+                _lib().call("ganet_sga_backward", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(saved), _p(mask),
+                            _p(gradOutput), _p(gradInput), *[_p(g) for g in grads], N, C, D, H, W, _stream())
+        return (gradInput, *grads)
+
+
+def _lga_dims(input, filters, radius):
+    if input.dim() == 5:
+        B, D = input.shape[0] * input.shape[1], input.shape[2]
+    elif input.dim() == 4:
+        B, D = input.shape[0], input.shape[1]
+    else:
+        raise ValueError("LGA expects a 4-D [N,D,H,W] or 5-D [N,C,D,H,W] input")
+    H, W = input.shape[-2:]
+    want = tuple(input.shape[:-3]) + (3 * (2 * radius + 1) ** 2, H, W)
+    if tuple(filters.shape) != want:
+        raise ValueError(f"LGA filters must be {want}, got {tuple(filters.shape)}")
+    return B, D, H, W
+
+
+class _LgaChain(Function):
+    """`passes` chained LGA passes sharing one filter tensor.  Backward walks the passes in
+    reverse, accumulating gradFilters (functions/GANet.py:189-203, 68-83)."""
+    passes = 1
+
+    @classmethod
+    def _fwd(cls, ctx, input, filters, radius):
+        _check(input, filters)
+        ctx.radius = radius
+        B, D, H, W = _lga_dims(input, filters, radius)
+        ins = [input]
+        with torch.cuda.device_of(input):
+            for _ in range(cls.passes):
+                y = torch.empty_like(input)
+                _lib().call("ganet_lga_forward", _p(ins[-1]), _p(filters), _p(y), B, D, H, W, radius, _stream())
+                ins.append(y)
+        ctx.save_for_backward(filters, *ins[:-1])
+        return ins[-1]
+
+    @staticmethod
+    def _bwd(ctx, gradOutput):
+        filters, *ins = ctx.saved_tensors
+        g = gradOutput.contiguous()
+        _check(g)
+        B, D, H, W = _lga_dims(ins[0], filters, ctx.radius)
+        with torch.cuda.device_of(g):
+            gradFilters = torch.empty_like(filters)
+            for k, xin in enumerate(reversed(ins)):
+                gx = torch.empty_like(xin)
+                _lib().call("ganet_lga_backward", _p(xin), _p(filters), _p(g), _p(gx), _p(gradFilters),
+                            B, D, H, W, ctx.radius, 1 if k > 0 else 0, _stream())
+                g = gx
+        return g, gradFilters, None
+
+
+def _make_lga(name, passes, doc):
+    def forward(ctx, input, filters, radius=1):
+        return cls._fwd(ctx, input, filters, radius)
+
+    def backward(ctx, gradOutput):
+        return _LgaChain._bwd(ctx, gradOutput)
+
+    cls = type(name, (_LgaChain,), {"passes": passes, "__doc__": doc,
+                                    "forward": staticmethod(forward), "backward": staticmethod(backward)})
+    return cls
+
+
+LgaFunction = _make_lga("LgaFunction", 1, "one LGA pass on [N,D,H,W] (functions/GANet.py:239-263)")
+Lga2Function = _make_lga("Lga2Function", 2, "two chained passes (functions/GANet.py:174-203); what the models use")
+Lga3Function = _make_lga("Lga3Function", 3, "three chained passes (functions/GANet.py:141-173)")
+Lga3dFunction = _make_lga("Lga3dFunction", 1, "one pass per (n,c) on [N,C,D,H,W] (functions/GANet.py:115-139)")
+Lga3d2Function = _make_lga("Lga3d2Function", 2, "two passes, 5-D (functions/GANet.py:84-113)")
+Lga3d3Function = _make_lga("Lga3d3Function", 3, "three passes, 5-D (functions/GANet.py:51-83)")
+Lgf2Function = Lga2Function
+
+
+class GetCostVolumeFunction(Function):
+    """cost[N,2C,maxdisp+1,H,W] from x, y [N,C,H,W] (modules/GANet.py:119-134), one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, y, ndisp):
+        _check(x, y)
+        if x.shape != y.shape or x.dim() != 4:
+            raise ValueError("GetCostVolume expects two [N,C,H,W] tensors of equal shape")
+        N, C, H, W = x.shape
+        ctx.dims = (N, C, ndisp, H, W)
+        with torch.cuda.device_of(x):
+            cost = torch.empty((N, 2 * C, ndisp, H, W), dtype=x.dtype, device=x.device)
+            _lib().call("ganet_cost_volume_forward", _p(x), _p(y), _p(cost), N, C, ndisp, H, W, _stream())
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        g = grad_cost.contiguous()
+        _check(g)
+        N, C, ndisp, H, W = ctx.dims
+        with torch.cuda.device_of(g):
+            gx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
+            gy = torch.empty_like(gx)
+            _lib().call("ganet_cost_volume_backward", _p(g), _p(gx), _p(gy), N, C, ndisp, H, W, _stream())
+        return gx, gy, None
+
+
+class DisparityRegressionFunction(Function):
+    """out[N,H,W] = sum_d d * x[N,D,H,W] (modules/GANet.py:142-148) without the per-call arange
+    upload / repeat / product volume."""
+
+    @staticmethod
+    def forward(ctx, x, ndisp):
+        _check(x)
+        if x.dim() != 4 or x.shape[1] != ndisp:
+            raise ValueError(f"DisparityRegression expects [N,{ndisp},H,W], got {tuple(x.shape)}")
+        N, D, H, W = x.shape
+        ctx.dims = (N, D, H, W)
+        with torch.cuda.device_of(x):
+            out = torch.empty((N, H, W), dtype=x.dtype, device=x.device)
+            _lib().call("ganet_disparity_regression_forward", _p(x), _p(out), N, D, H, W, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous()
+        _check(g)
+        N, D, H, W = ctx.dims
+        with torch.cuda.device_of(g):
+            gx = torch.empty((N, D, H, W), dtype=g.dtype, device=g.device)
+            _lib().call("ganet_disparity_regression_backward", _p(g), _p(gx), N, D, H, W, _stream())
+        return gx, None
+
+
+class MyLoss2Function(Function):
+    """Robust loss of functions/GANet.py:264-289 (pure tensor ops; kept for API parity)."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, thresh=1, alpha=2):
+        ctx.thresh, ctx.alpha = thresh, alpha
+        diff = input1 - input2
+        temp = torch.abs(diff)
+        lo = temp < thresh
+        temp[lo] = temp[lo] ** 2 / thresh
+        tag = (temp <= thresh + alpha) & (temp >= thresh)
+        temp[tag] = temp[tag] * 2 - (temp[tag] - thresh) ** 2 / (2.0 * alpha) - thresh
+        temp[temp > thresh + alpha] += alpha / 2.0
+        ctx.save_for_backward(diff)
+        return torch.mean(temp)
+
+    @staticmethod
+    def backward(ctx, gradOutput):
+        diff, = ctx.saved_tensors
+        scale = torch.abs(diff)
+        scale[scale > ctx.thresh + ctx.alpha] = 1
+        tag = (scale <= ctx.thresh + ctx.alpha) & (scale >= ctx.thresh)
+        scale[tag] = 2 - (scale[tag] - ctx.thresh) / ctx.alpha
+        tag = scale < ctx.thresh
+        scale[tag] = 2 * scale[tag] / ctx.thresh
+        sign = torch.sign(diff)
+        grad = sign * scale * gradOutput / scale.numel()
+        return grad, None, None, None
+
+
+class MyLossFunction(Function):
+    """functions/GANet.py:291-310."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, upper_thresh=5, lower_thresh=1):
+        ctx.upper_thresh, ctx.lower_thresh = upper_thresh, lower_thresh
+        diff = input1 - input2
+        ctx.save_for_backward(diff)
+        return torch.mean(torch.abs(diff))
+
+    @staticmethod
+    def backward(ctx, gradOutput):
+        diff, = ctx.saved_tensors
+        scale = torch.abs(diff)
+        scale[scale > ctx.upper_thresh] = 1
+        tag = (scale <= ctx.upper_thresh) & (scale >= ctx.lower_thresh)
+        scale[tag] = 2 - torch.abs(scale[tag] - (ctx.upper_thresh + ctx.lower_thresh) / 2.) / 2.
+        grad = torch.sign(diff) * scale * gradOutput
+        return grad, None, None, None

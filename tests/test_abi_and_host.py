@@ -1,0 +1,108 @@
+"""CPU-side checks of the boundary: the gfx950 library builds, loads without a GPU and exports
+every symbol include/ganet_hip.h declares; the host layer mirrors the reference's names; the
+product refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ganet_amd import build
+    return build.build_hip()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "ganet_hip.h")).read()
+    declared = set(re.findall(r"\b(ganet_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in ganet_hip.h but not exported"
+    from ganet_amd import _native
+    assert declared == set(_native.EXPORTS)
+    assert lib.ganet_abi_version() == _native.ABI_VERSION
+    assert lib.ganet_is_simulator() == 0
+
+
+def test_library_contains_gfx950_code_object(built_lib):
+    blob = open(built_lib, "rb").read()
+    assert b"gfx950" in blob, "no gfx950 code object in libganet_hip.so"
+
+
+def test_reference_names_are_mirrored():
+    import ganet_amd.functions.GANet as Fn
+    import ganet_amd.modules.GANet as M
+    from ganet_amd import ext
+    for n in ["SgaFunction", "LgaFunction", "Lga2Function", "Lga3Function", "Lga3dFunction", "Lga3d2Function",
+              "Lga3d3Function", "MyLossFunction", "MyLoss2Function"]:
+        assert hasattr(Fn, n)
+    for n in ["SGA", "LGA", "LGA2", "LGA3", "LGA3D", "LGA3D2", "LGA3D3", "GetCostVolume", "DisparityRegression",
+              "MyNormalize", "MyLoss", "MyLoss2"]:
+        assert hasattr(M, n)
+    for n in ["sga_cuda_forward", "sga_cuda_backward", "lga_cuda_forward", "lga_cuda_backward",
+              "lga3d_cuda_forward", "lga3d_cuda_backward"]:          # GANet_cuda.cpp:69-74
+        assert callable(getattr(ext, n))
+    assert M.GetCostVolume(192).maxdisp == 193 and M.LGA2(radius=2).radius == 2
+    import libs.GANet.modules.GANet as L
+    assert L.SGA is M.SGA
+    from libs.sync_bn.modules.sync_bn import BatchNorm2d, BatchNorm3d  # noqa: F401
+
+
+def test_no_cpu_fallback():
+    import torch
+    from ganet_amd.modules.GANet import SGA
+    x, g = torch.randn(1, 1, 3, 2, 4), torch.randn(1, 1, 5, 2, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SGA()(x, g, g, g, g)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from ganet_amd._native import CApi, GanetError
+    with pytest.raises(GanetError, match="no CPU fallback"):
+        CApi(str(tmp_path / "libganet_hip.so"))
+
+
+def test_pure_torch_losses_match_reference_formulas():
+    import torch
+    from ganet_amd.modules.GANet import MyLoss2, MyNormalize
+    torch.manual_seed(0)
+    a = (torch.randn(64) * 3).requires_grad_()
+    b = torch.randn(64) * 3
+    loss = MyLoss2(thresh=1, alpha=2)(a, b)
+    loss.backward()
+    # the reference applies its three masked updates SEQUENTIALLY on one buffer
+    # (functions/GANet.py:269-274), so a mid-range value pushed above thresh+alpha by the
+    # second update also receives the third one; restate that per element
+    vals = []
+    for t in (a - b).detach().abs().tolist():
+        if t < 1:
+            t = t * t / 1
+        if 1 <= t <= 3:
+            t = t * 2 - (t - 1) ** 2 / 4.0 - 1
+        if t > 3:
+            t += 1.0
+        vals.append(t)
+    assert abs(loss.item() - sum(vals) / len(vals)) < 1e-5
+    assert a.grad.abs().max() > 0
+    y = MyNormalize(1)(torch.tensor([[1.0, -3.0], [0.0, 0.0]]))
+    assert torch.allclose(y[0], torch.tensor([0.25, -0.75]), atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models/GANet_deep.py"), reason="reference tree absent")
+def test_reference_models_import_on_top_of_the_drop_in(monkeypatch):
+    """models/GANet_deep.py and GANet11.py construct unchanged with this repo's `libs` package."""
+    monkeypatch.syspath_prepend("/root/reference")
+    monkeypatch.syspath_prepend(ROOT)
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        monkeypatch.delitem(sys.modules, m)
+    from models.GANet_deep import GANet
+    net = GANet(192)
+    assert sum(p.numel() for p in net.parameters()) == 6580112
+    import ganet_amd.modules.GANet as M
+    assert isinstance(net.cost_agg.sga1.SGA, M.SGA)

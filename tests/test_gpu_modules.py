@@ -1,0 +1,156 @@
+"""GPU tests of the drop-in operator API (ganet_amd.functions / ganet_amd.modules / ganet_amd.ext,
+mirroring libs/GANet/{functions,modules}/GANet.py and the pybind module of GANet_cuda.cpp)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("save_mode", ["", "recompute"])
+def test_sga_module_autograd(torch_mod, port_oracle, monkeypatch, save_mode):
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.modules.GANet import SGA
+    monkeypatch.setenv("GANET_SGA_SAVE", save_mode)
+    torch.manual_seed(123)
+    x = torch.randn(2, 3, 33, 10, 24, device="cuda", requires_grad=True)
+    gs = [F.normalize(torch.randn(2, 3, 5, 10, 24, device="cuda"), p=1, dim=2).requires_grad_() for _ in range(4)]
+    go = torch.randn_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # a non-default torch stream
+        out = SGA()(x, *gs)
+        out.backward(go)
+    side.synchronize()
+    o_out, o_tmp, o_mask = port_oracle.sga_forward(_np(x), *[_np(g) for g in gs])
+    o_g = port_oracle.sga_backward(_np(x), *[_np(g) for g in gs], o_tmp, o_mask, _np(go))
+    assert np.array_equal(_np(out), o_out)
+    for t, want in zip([x] + gs, o_g):
+        assert np.abs(_np(t.grad) - want).max() <= pc.TOL
+
+
+@pytest.mark.parametrize("cls_name,passes,five_d", [("LGA", 1, False), ("LGA2", 2, False), ("LGA3", 3, False),
+                                                    ("LGA3D", 1, True), ("LGA3D2", 2, True), ("LGA3D3", 3, True)])
+def test_lga_modules_autograd(torch_mod, port_oracle, cls_name, passes, five_d):
+    torch = torch_mod
+    import torch.nn.functional as F
+    import ganet_amd.modules.GANet as M
+    torch.manual_seed(7)
+    shape = (2, 3, 9, 12, 40) if five_d else (2, 9, 12, 40)
+    fshape = shape[:-3] + (75,) + shape[-2:]
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    f = F.normalize(torch.randn(fshape, device="cuda"), p=1, dim=len(shape) - 3).requires_grad_()
+    gy = torch.randn_like(x)
+    gy_keep = gy.clone()
+    y = getattr(M, cls_name)(radius=2)(x, f)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    assert torch.equal(gy, gy_keep), "gradOutput must not be modified (SURVEY F7)"
+    o_y, ins = port_oracle.lga_chain_forward(_np(x), _np(f), 2, passes)
+    o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy), 2)
+    assert np.abs(_np(y) - o_y).max() <= pc.TOL
+    assert np.abs(_np(x.grad) - o_gx).max() <= pc.TOL
+    assert np.abs(_np(f.grad) - o_gf).max() <= pc.TOL
+
+
+def test_cost_volume_and_regression_modules(torch_mod):
+    """Against a torch restatement of modules/GANet.py:119-148 (slice-assign loop / sum(x*disp))."""
+    torch = torch_mod
+    from ganet_amd.modules.GANet import DisparityRegression, GetCostVolume
+    torch.manual_seed(1)
+    maxdisp = 12
+    x = torch.randn(2, 8, 10, 40, device="cuda", requires_grad=True)
+    y = torch.randn(2, 8, 10, 40, device="cuda", requires_grad=True)
+    cost = GetCostVolume(maxdisp)(x, y)
+    xr, yr = x.detach().clone().requires_grad_(), y.detach().clone().requires_grad_()
+    ref = x.new_zeros(2, 16, maxdisp + 1, 10, 40)
+    for i in range(maxdisp + 1):
+        if i > 0:
+            ref[:, :8, i, :, i:] = xr[:, :, :, i:]
+            ref[:, 8:, i, :, i:] = yr[:, :, :, :-i]
+        else:
+            ref[:, :8, i] = xr
+            ref[:, 8:, i] = yr
+    assert torch.equal(cost, ref)
+    g = torch.randn_like(cost)
+    cost.backward(g)
+    ref.backward(g)
+    assert torch.allclose(x.grad, xr.grad, atol=1e-5) and torch.allclose(y.grad, yr.grad, atol=1e-5)
+    p = torch.softmax(torch.randn(2, maxdisp + 1, 10, 40, device="cuda"), 1).requires_grad_()
+    out = DisparityRegression(maxdisp)(p)
+    disp = torch.arange(maxdisp + 1, device="cuda", dtype=torch.float32).view(1, -1, 1, 1)
+    pr = p.detach().clone().requires_grad_()
+    want = torch.sum(pr * disp, 1)
+    assert torch.allclose(out, want, atol=1e-5)
+    go = torch.randn_like(out)
+    out.backward(go)
+    want.backward(go)
+    assert torch.allclose(p.grad, pr.grad, atol=1e-6)
+
+
+def test_ext_module_reference_buffer_contract(torch_mod, port_oracle):
+    """The six functions of the reference's pybind module, called exactly as the reference's
+    functions/GANet.py calls them (zero-filled caller buffers, aliasing in the LGA2 backward)."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd import ext as GANet
+    torch.manual_seed(3)
+    x = torch.randn(1, 2, 17, 6, 12, device="cuda")
+    gs = [F.normalize(torch.randn(1, 2, 5, 6, 12, device="cuda"), p=1, dim=2) for _ in range(4)]
+    output, temp_out, mask = (torch.zeros_like(x) for _ in range(3))
+    assert GANet.sga_cuda_forward(x, *gs, temp_out, output, mask) == 1
+    go = torch.randn_like(x)
+    gradInput = torch.zeros_like(x)
+    grads = [torch.zeros_like(g) for g in gs]
+    temp_grad = torch.zeros_like(x)
+    max_idx = torch.zeros(1, 2, 6, 12, device="cuda")
+    saved_tmp = temp_out.clone()
+    GANet.sga_cuda_backward(x, *gs, temp_out, mask, max_idx, go, temp_grad, gradInput, *grads)
+    torch.cuda.synchronize()
+    o_out, o_tmp, o_mask = port_oracle.sga_forward(_np(x), *[_np(g) for g in gs])
+    o_g = port_oracle.sga_backward(_np(x), *[_np(g) for g in gs], o_tmp, o_mask, _np(go))
+    assert np.array_equal(_np(output), o_out) and np.array_equal(_np(mask), o_mask)
+    assert np.array_equal(_np(saved_tmp), o_tmp)
+    for t, want in zip([gradInput] + grads, o_g):
+        assert np.abs(_np(t) - want).max() <= pc.TOL
+    # LGA2 exactly as Lga2Function.backward chains it (functions/GANet.py:189-203)
+    xl = torch.randn(1, 6, 8, 36, device="cuda")
+    f = F.normalize(torch.randn(1, 75, 8, 36, device="cuda"), p=1, dim=1)
+    t1, y = torch.zeros_like(xl), torch.zeros_like(xl)
+    GANet.lga_cuda_forward(xl, f, t1, 2)
+    GANet.lga_cuda_forward(t1, f, y, 2)
+    gy = torch.randn_like(xl)
+    gy0 = gy.clone()
+    gradFilters = torch.zeros_like(f)
+    o_y, ins = port_oracle.lga_chain_forward(_np(xl), _np(f), 2, 2)
+    o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy0), 2)
+    GANet.lga_cuda_backward(t1, f, gy, t1, gradFilters, 2)        # gradInput aliases input
+    GANet.lga_cuda_backward(xl, f, t1, gy, gradFilters, 2)        # result lands in gradOutput's buffer
+    torch.cuda.synchronize()
+    assert np.abs(_np(y) - o_y).max() <= pc.TOL
+    assert np.abs(_np(gy) - o_gx).max() <= pc.TOL
+    assert np.abs(_np(gradFilters) - o_gf).max() <= pc.TOL
+
+
+def test_cpu_tensors_fail_loudly(torch_mod):
+    torch = torch_mod
+    from ganet_amd.modules.GANet import LGA2, SGA
+    x = torch.randn(1, 1, 3, 2, 4)
+    g = torch.randn(1, 1, 5, 2, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SGA()(x, g, g, g, g)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        LGA2(2)(torch.randn(1, 3, 4, 4), torch.randn(1, 75, 4, 4))

@@ -1,0 +1,205 @@
+"""GPU parity tests (pytest -m gpu, run on a real MI355X through gpurun): the gfx950 build of
+libganet_hip.so driven through its C ABI, against the committed golden fixtures (generated from
+the reference's own kernel bodies) and the CPU oracle on the same seeded inputs.
+Bar: direction mask / forward volumes bit-exact, fp32 gradients within 1e-4 max-abs."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from golden_util import lga_case_names, load, sga_case_names
+
+pytestmark = pytest.mark.gpu
+
+
+class TorchDev:
+    def __init__(self):
+        import torch
+        self.torch = torch
+        assert torch.cuda.is_available()
+        self.device = torch.device("cuda:0")
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def to(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def _dt(self, dtype):
+        return {np.float32: self.torch.float32, np.uint8: self.torch.uint8, np.int32: self.torch.int32}[dtype]
+
+    def empty(self, shape, dtype=np.float32):
+        # poison so that an element the kernel fails to write is noticed
+        t = self.torch.empty(tuple(shape), dtype=self._dt(dtype), device=self.device)
+        return t.fill_(float("nan")) if dtype == np.float32 else t.fill_(113)
+
+    def zeros(self, shape, dtype=np.float32):
+        return self.torch.zeros(tuple(shape), dtype=self._dt(dtype), device=self.device)
+
+    def ptr(self, t):
+        return t.data_ptr()
+
+    def host(self, t):
+        return t.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="module")
+def api():
+    from ganet_amd import _native
+    lib = _native.lib()
+    assert not lib.is_simulator, "GPU tests must run the gfx950 build"
+    assert lib.path.endswith("ganet_amd/libganet_hip.so")
+    return lib
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return TorchDev()
+
+
+def test_dpp_lane_patterns(api, dev):
+    scratch = dev.zeros((8 * 64,), np.int32)
+    host = np.zeros(8 * 64, np.int32)
+    api.call("ganet_selftest_dpp", scratch.data_ptr(), host.ctypes.data, dev.stream)
+
+
+@pytest.mark.parametrize("name", sga_case_names())
+def test_sga_golden(api, dev, name):
+    z = load("sga_golden.npz")
+    x, go = z[f"{name}.x"], z[f"{name}.go"]
+    gs = [z[f"{name}.g{d}"] for d in range(4)]
+    want = {"out": z[f"{name}.out"], "mask": z[f"{name}.mask"], "tmp": z[f"{name}.tmp"], "gx": z[f"{name}.gx"]}
+    for d in range(4):
+        want[f"A{d}"] = z[f"{name}.A{d}"]
+        want[f"gw{d}"] = z[f"{name}.gw{d}"]
+    pc.check_sga_forward_backward(api, dev, x, gs, go, want)
+    pc.check_sga_compat(api, dev, x, gs, go, want)
+
+
+def test_sga_cfg1_golden_forward(api, dev):
+    """BASELINE.json configs[0]: 1x48x48x48 (C=1) forward."""
+    z = load("sga_cfg1_golden.npz")
+    _, _, _, out, mask = pc.run_sga_forward(api, dev, z["x"], [z[f"g{d}"] for d in range(4)])
+    assert np.array_equal(dev.host(out), z["out"])
+    assert np.array_equal(dev.host(mask), z["mask"])
+
+
+def _oracle_want(oracle, x, gs, go):
+    out, tmp, mask = oracle.sga_forward(x, *gs)
+    grads = oracle.sga_backward(x, *gs, tmp, mask, go)
+    want = {"out": out, "mask": mask.astype(np.uint8), "tmp": tmp, "gx": grads[0]}
+    for d in range(4):
+        want[f"gw{d}"] = grads[1 + d]
+    return want
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 65, 20, 52), (2, 2, 33, 40, 104), (1, 2, 48, 17, 30), (1, 1, 193, 6, 12),
+                                   (1, 5, 9, 64, 8), (3, 1, 2, 7, 260)])
+def test_sga_random_vs_oracle(api, dev, port_oracle, shape):
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+
+
+@pytest.mark.parametrize("gd", [4, 8, 16])
+def test_sga_lane_layouts(api, dev, port_oracle, gd):
+    api.set_option("GANET_SGA_GD", gd)
+    try:
+        for shape in [(1, 2, 65, 9, 24), (1, 2, 33, 10, 20)]:
+            x, gs, go = pc.sga_inputs(shape, seed=gd)
+            pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+    finally:
+        api.set_option("GANET_SGA_GD", 16)
+
+
+def test_sga_single_stream_equals_multi_stream(api, dev):
+    x, gs, _ = pc.sga_inputs((1, 4, 33, 16, 40), seed=3)
+    res = []
+    for streams in (0, 1):
+        api.set_option("GANET_SGA_STREAMS", streams)
+        _, _, A, out, mask = pc.run_sga_forward(api, dev, x, gs)
+        res.append((dev.host(A), dev.host(out), dev.host(mask)))
+    api.set_option("GANET_SGA_STREAMS", 1)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", lga_case_names())
+def test_lga_golden(api, dev, name):
+    z = load("lga_golden.npz")
+    r, passes = (int(v) for v in z[f"{name}.meta"])
+    want = {"y": z[f"{name}.y"], "gx": z[f"{name}.gx"], "gf": z[f"{name}.gf"]}
+    pc.check_lga_chain(api, dev, z[f"{name}.x"], z[f"{name}.f"], z[f"{name}.gy"], r, passes, want)
+
+
+@pytest.mark.parametrize("shape,r,passes", [((1, 193, 24, 72), 2, 2), ((2, 33, 41, 67), 2, 1), ((1, 7, 64, 128), 1, 3),
+                                            ((1, 12, 19, 33), 3, 1), ((2, 3, 17, 9, 40), 2, 2)])
+def test_lga_random_vs_oracle(api, dev, port_oracle, shape, r, passes):
+    rng = np.random.default_rng(sum(shape) + r)
+    fs = list(shape)
+    fs[-3] = 3 * (2 * r + 1) ** 2
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal(fs), -3)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y, ins = port_oracle.lga_chain_forward(x, f, r, passes)
+    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, r)
+    pc.check_lga_chain(api, dev, x, f, gy, r, passes, {"y": y, "gx": gx, "gf": gf})
+
+
+def test_full_size_cfg2_against_oracle(api, dev, port_oracle):
+    """BASELINE.json configs[1] at full size: SGA [1,32,65,80,208] and LGA2 [1,193,240,624]."""
+    x, gs, go = pc.sga_inputs((1, 32, 65, 80, 208), seed=123)
+    err = pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+    print("cfg2 SGA max-abs errors:", err)
+    rng = np.random.default_rng(123)
+    shape = (1, 193, 240, 624)
+    xl = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((1, 75, 240, 624)), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y, ins = port_oracle.lga_chain_forward(xl, f, 2, 2)
+    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+    err = pc.check_lga_chain(api, dev, xl, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+    print("cfg2 LGA2 max-abs errors:", err)
+
+
+def test_full_size_properties(api, dev):
+    """Size-independent properties at the full cfg2 shapes (no oracle involved):
+    SGA is positively homogeneous -- scaling x by 2 scales every volume by exactly 2 and leaves
+    the direction mask unchanged; LGA is bilinear, so <y, gy> == <x, gX> == <f, gF>."""
+    torch = dev.torch
+    x, gs, _ = pc.sga_inputs((1, 32, 65, 80, 208), seed=5)
+    _, _, _, out1, mask1 = pc.run_sga_forward(api, dev, x, gs)
+    _, _, _, out2, mask2 = pc.run_sga_forward(api, dev, 2.0 * x, gs)
+    assert torch.equal(out2, 2.0 * out1) and torch.equal(mask1, mask2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, D, H, W = 1, 193, 240, 624
+    xl = torch.randn((B, D, H, W), device="cuda", generator=g)
+    f = torch.nn.functional.normalize(torch.randn((B, 75, H, W), device="cuda", generator=g), p=1, dim=1)
+    gy = torch.randn((B, D, H, W), device="cuda", generator=g)
+    y, gx, gf = torch.empty_like(xl), torch.empty_like(xl), torch.empty_like(f)
+    api.call("ganet_lga_forward", xl.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, dev.stream)
+    api.call("ganet_lga_backward", xl.data_ptr(), f.data_ptr(), gy.data_ptr(), gx.data_ptr(), gf.data_ptr(),
+             B, D, H, W, 2, 0, dev.stream)
+    torch.cuda.synchronize()
+    a = (y.double() * gy.double()).sum().item()
+    b = (xl.double() * gx.double()).sum().item()
+    c = (f.double() * gf.double()).sum().item()
+    scale = (y.double().abs() * gy.double().abs()).sum().item()
+    assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
+
+
+def test_cost_volume_and_regression(api, dev, port_oracle):
+    torch = dev.torch
+    rng = np.random.default_rng(11)
+    N, C, H, W, maxdisp = 2, 32, 20, 52, 64
+    Dn = maxdisp + 1
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dx, dy = dev.to(x), dev.to(y)
+    cost = dev.empty((N, 2 * C, Dn, H, W))
+    api.call("ganet_cost_volume_forward", dx.data_ptr(), dy.data_ptr(), cost.data_ptr(), N, C, Dn, H, W, dev.stream)
+    assert np.array_equal(dev.host(cost), port_oracle.cost_volume(x, y, maxdisp))
+    p = rng.random((N, 193, H, W)).astype(np.float32)
+    out = dev.empty((N, H, W))
+    api.call("ganet_disparity_regression_forward", dev.to(p).data_ptr(), out.data_ptr(), N, 193, H, W, dev.stream)
+    np.testing.assert_allclose(dev.host(out), port_oracle.disparity_regression(p, 192), rtol=1e-5, atol=1e-4)
+    assert torch.cuda.is_available()
