@@ -5,6 +5,7 @@
 #include "lga_kernels.h"
 #include "misc_kernels.h"
 #include "sga_kernels.h"
+#include "sga_row_kernels.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,8 +19,12 @@
 #if defined(GA_HIPSIM)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
   hipsim::launch((grid), (block), 0, [=]() { kern(__VA_ARGS__); })
+#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
+  hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 #define GA_EXPORT extern "C"
 #else
+#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
 #define GA_EXPORT extern "C" __attribute__((visibility("default")))
@@ -60,10 +65,16 @@ int check_launch(const char *what)
   } while (0)
 
 // ---- options ------------------------------------------------------------------
+// Defaults measured on MI355X at [1,32,65,80,208] (profiles/r1_tune_sga.txt): vertical scans
+// want FEW lanes per scanline (GD=4: each wave load covers 64 contiguous bytes per plane),
+// horizontal scans want many (GD=16: more waves, float4 per lane along W).  Running the four
+// directions on four streams was slower than back-to-back launches (0.97 vs 0.87 ms).
 struct Options {
-  int gd = 16;
-  int streams = 1;
-  int block_v = 256;
+  int gd_v = 4;
+  int gd_h = 16;
+  int streams = 0;
+  int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
+  int block_v = 128;
   int block_h = 64;
 };
 Options g_opt;
@@ -75,8 +86,10 @@ void load_env_options()
     const char *v = getenv(name);
     if (v && *v) dst = atoi(v);
   };
-  geti("GANET_SGA_GD", g_opt.gd);
+  geti("GANET_SGA_GD_V", g_opt.gd_v);
+  geti("GANET_SGA_GD_H", g_opt.gd_h);
   geti("GANET_SGA_STREAMS", g_opt.streams);
+  geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
   geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
@@ -117,7 +130,7 @@ int get_pool(SidePool **out)
 // ---- SGA kernel selection -----------------------------------------------------------
 // (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
 #define GA_SGA_PAIRS(X) \
-  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 9) X(4, 17)
+  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 5) X(4, 9) X(4, 17)
 
 constexpr int fwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
 constexpr int fwd_nv(int dpl) { return dpl <= 5 ? 2 : 1; }
@@ -218,11 +231,62 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
   return GANET_OK;
 }
 
+// ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
+constexpr int ROW_SBH = 16;
+constexpr size_t ROW_SMEM_MAX = 60 * 1024;
+
+size_t row_smem_fwd(int D) { return sizeof(float) * ((size_t)2 * D * RowCfg<ROW_SBH>::RS + 5 * ROW_SBH); }
+size_t row_smem_bwd(int D)
+{
+  const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH>::PP + 1) + 3) & ~(size_t)3;
+  return sizeof(float) * ((size_t)4 * D * RowCfg<ROW_SBH>::RS + mask_words + 10 * ROW_SBH);
+}
+
+bool rowwave_ok(int D, int W, int dir, size_t smem)
+{
+  return opts().rowwave && dir >= 2 && W % 4 == 0 && D <= 256 && smem <= ROW_SMEM_MAX;
+}
+
+int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  RowGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const int dpl = (D + 63) / 64, desc = dir == 3 ? 1 : 0;
+  const size_t smem = row_smem_fwd(D);
+  const dim3 grid(S * H), block(64);
+  switch (dpl) {
+    case 1: GA_LAUNCH_SMEM((sga_row_fwd<1, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
+    case 2: GA_LAUNCH_SMEM((sga_row_fwd<2, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
+    case 3: GA_LAUNCH_SMEM((sga_row_fwd<3, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
+    default: GA_LAUNCH_SMEM((sga_row_fwd<4, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
+  }
+  return check_launch("sga row forward");
+}
+
+int row_bwd(const float *x, const float *g, const float *A, const uint8_t *mask, const float *gout,
+            float *gx, float *gw, int S, int D, int H, int W, int dir, int accumulate, hipStream_t st)
+{
+  RowGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const int dpl = (D + 63) / 64, desc = dir == 2 ? 1 : 0;   // backward of `right` walks w down
+  const size_t smem = row_smem_bwd(D);
+  const dim3 grid(S * H), block(64);
+  switch (dpl) {
+    case 1: GA_LAUNCH_SMEM((sga_row_bwd<1, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
+    case 2: GA_LAUNCH_SMEM((sga_row_bwd<2, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
+    case 3: GA_LAUNCH_SMEM((sga_row_bwd<3, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
+    default: GA_LAUNCH_SMEM((sga_row_bwd<4, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
+  }
+  return check_launch("sga row backward");
+}
+
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
              hipStream_t st)
 {
+  if (rowwave_ok(D, W, dir, row_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A))
+    return row_fwd(x, g, A, N * C, D, H, W, dir, st);
   int gd, dpl;
-  if (!pick_pair(D, opts().gd, &gd, &dpl))
+  if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
 #define X(G, P) \
   if (gd == (G) && dpl == (P)) return launch_scan_fwd<G, P>(x, g, A, N * C, D, H, W, dir, st);
@@ -235,8 +299,11 @@ int scan_bwd(const float *x, const float *g, const float *A, const uint8_t *mask
              float *gx, float *gw, int N, int C, int D, int H, int W, int dir, int accumulate,
              hipStream_t st)
 {
+  if (rowwave_ok(D, W, dir, row_smem_bwd(D)) && aligned16(x) && aligned16(g) && aligned16(A) &&
+      aligned16(gout) && aligned16(gx) && aligned16(gw) && (((uintptr_t)mask & 3) == 0))
+    return row_bwd(x, g, A, mask, gout, gx, gw, N * C, D, H, W, dir, accumulate, st);
   int gd, dpl;
-  if (!pick_pair(D, opts().gd, &gd, &dpl))
+  if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
 #define X(G, P)                  \
   if (gd == (G) && dpl == (P))   \
@@ -321,10 +388,12 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 {
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
-  if (!strcmp(name, "GANET_SGA_GD")) {
-    if (value != 4 && value != 8 && value != 16) return fail(GANET_E_INVALID, "GANET_SGA_GD must be 4, 8 or 16");
-    g_opt.gd = value;
+  if (!strcmp(name, "GANET_SGA_GD") || !strcmp(name, "GANET_SGA_GD_V") || !strcmp(name, "GANET_SGA_GD_H")) {
+    if (value != 4 && value != 8 && value != 16) return fail(GANET_E_INVALID, "%s must be 4, 8 or 16", name);
+    if (strcmp(name, "GANET_SGA_GD_H")) g_opt.gd_v = value;
+    if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
   } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);

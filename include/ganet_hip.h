@@ -107,7 +107,8 @@ int ganet_lga_forward(const float *x, const float *f, float *y,
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,
- * functions/GANet.py:197-199).  gx must not alias x or gy.
+ * functions/GANet.py:197-199).  gx may alias x (the reference's chained
+ * backward does); it must not alias gy.
  * Replaces: lga_cuda_backward / lga3d_cuda_backward (GANet_cuda.cpp:5-28) ->
  *           lga_filter_backward (:1177-1216) + cudaMemset + lga_data_backward
  *           (:1218-1269). */
@@ -140,8 +141,9 @@ int ganet_disparity_regression_backward(const float *grad_out, float *grad_x,
 int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
 
 /* Tuning knobs (also read from the environment at first use):
- *   GANET_SGA_GD=4|8|16   lanes per scanline            (default 16)
- *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 1)
+ *   GANET_SGA_GD_V / GANET_SGA_GD_H = 4|8|16  lanes per scanline, vertical / horizontal scans
+ *                         (defaults 4 / 16; GANET_SGA_GD sets both through ganet_set_option)
+ *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
  *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans */
 int ganet_set_option(const char *name, int value);
 

@@ -113,6 +113,20 @@ inline int update_dpp(int old, int src, int ctrl)
   return v;
 }
 
+// ds_bpermute_b32: every lane reads `src` of lane `src_lane` (mod 64) of its wave
+inline int bpermute(int src_lane, int src)
+{
+  State &s = S();
+  const int tid = flat_tid(), wave = tid >> 6;
+  const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
+  s.xchg[tid] = src;
+  barrier_wait(s.wave_bar[wave], wsize);
+  const int sl = src_lane & 63;
+  const int v = sl < wsize ? s.xchg[wave * 64 + sl] : 0;
+  barrier_wait(s.wave_bar[wave], wsize);
+  return v;
+}
+
 inline void fiber_entry()
 {
   State &s = S();

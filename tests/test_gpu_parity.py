@@ -111,6 +111,18 @@ def test_sga_lane_layouts(api, dev, port_oracle, gd):
         api.set_option("GANET_SGA_GD", 16)
 
 
+@pytest.mark.parametrize("rowwave", [0, 1])
+def test_sga_horizontal_kernel_families(api, dev, port_oracle, rowwave):
+    """float4-per-lane segments vs one-wavefront-per-row LDS-staged kernels (right / left)."""
+    api.set_option("GANET_SGA_ROWWAVE", rowwave)
+    try:
+        for shape in [(1, 2, 65, 9, 48), (2, 1, 33, 5, 104), (1, 1, 130, 3, 24), (1, 3, 7, 4, 20)]:
+            x, gs, go = pc.sga_inputs(shape, seed=17 + rowwave)
+            pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+    finally:
+        api.set_option("GANET_SGA_ROWWAVE", 1)
+
+
 def test_sga_single_stream_equals_multi_stream(api, dev):
     x, gs, _ = pc.sga_inputs((1, 4, 33, 16, 40), seed=3)
     res = []
@@ -118,7 +130,7 @@ def test_sga_single_stream_equals_multi_stream(api, dev):
         api.set_option("GANET_SGA_STREAMS", streams)
         _, _, A, out, mask = pc.run_sga_forward(api, dev, x, gs)
         res.append((dev.host(A), dev.host(out), dev.host(mask)))
-    api.set_option("GANET_SGA_STREAMS", 1)
+    api.set_option("GANET_SGA_STREAMS", 0)
     for a, b in zip(*res):
         assert np.array_equal(a, b)
 

@@ -18,6 +18,16 @@ def sim():
 DEV = pc.NumpyDev()
 
 
+def _oracle_want(oracle, x, gs, go):
+    out, tmp, mask = oracle.sga_forward(x, *gs)
+    grads = oracle.sga_backward(x, *gs, tmp, mask, go)
+    want = {"out": out, "mask": mask.astype(np.uint8), "tmp": tmp, "gx": grads[0]}
+    for d in range(4):
+        want[f"gw{d}"] = grads[1 + d]
+        want[f"A{d}"] = oracle.sga_scan(x, gs[d], d)
+    return want
+
+
 @pytest.mark.parametrize("direction", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(1, 2, 5, 4, 8), (2, 1, 17, 3, 6), (1, 3, 1, 2, 4), (1, 1, 35, 5, 4)])
 def test_scan_matches_oracle_bit_exact(sim, port_oracle, shape, direction):
@@ -61,6 +71,20 @@ def test_reference_buffer_contract(sim, name):
     pc.check_sga_compat(sim, DEV, x, gs, go, want)
 
 
+@pytest.mark.parametrize("rowwave", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 2, 6, 3, 4), (1, 1, 20, 2, 20), (2, 1, 65, 2, 36), (1, 1, 130, 1, 8), (1, 2, 33, 3, 48)])
+def test_horizontal_kernel_families(sim, port_oracle, shape, rowwave):
+    """Both horizontal implementations (float4-per-lane segments / one wavefront per row with
+    LDS-staged tiles) against the oracle, incl. partial batches and D > 64 (2+ disparities/lane)."""
+    sim.set_option("GANET_SGA_ROWWAVE", rowwave)
+    try:
+        x, gs, go = pc.sga_inputs(shape, seed=11 + rowwave)
+        err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_SGA_ROWWAVE", 1)
+
+
 def test_dpp_selftest(sim):
     scratch = np.zeros(8 * 64, np.int32)
     host = np.zeros(8 * 64, np.int32)
@@ -77,16 +101,6 @@ def test_errors_are_reported(sim):
         sim.call("ganet_sga_scan_forward", None, g.ctypes.data, x.ctypes.data, 1, 1, 3, 1, 1, 0, None)
     with pytest.raises(GanetError, match="dir"):
         sim.call("ganet_sga_scan_forward", x.ctypes.data, g.ctypes.data, x.ctypes.data, 1, 1, 3, 1, 1, 7, None)
-
-
-def _oracle_want(oracle, x, gs, go):
-    out, tmp, mask = oracle.sga_forward(x, *gs)
-    grads = oracle.sga_backward(x, *gs, tmp, mask, go)
-    want = {"out": out, "mask": mask.astype(np.uint8), "tmp": tmp, "gx": grads[0]}
-    for d in range(4):
-        want[f"gw{d}"] = grads[1 + d]
-        want[f"A{d}"] = oracle.sga_scan(x, gs[d], d)
-    return want
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 6, 3, 4), (1, 1, 20, 2, 20), (2, 2, 3, 5, 36), (1, 1, 70, 2, 8),
