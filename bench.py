@@ -86,6 +86,8 @@ def stage_timings(inp, iters=5):
     A = torch.empty((4,) + tuple(x.shape), device=x.device)
     out = torch.empty_like(x)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    kp = torch.empty((4, N, C, H, W), dtype=torch.int16, device=x.device)
+    G = torch.empty_like(A)
     gx = torch.empty_like(x)
     gw = [torch.empty_like(g) for g in gs]
     B, DL, HL, WL = xl.shape
@@ -108,13 +110,20 @@ def stage_timings(inp, iters=5):
     for d in range(4):
         res[f"sga_scan_fwd_{names[d]}"] = timed(lambda d=d: lib.call(
             "ganet_sga_scan_forward", x.data_ptr(), gs[d].data_ptr(), A[d].data_ptr(), N, C, D, H, W, d, st))
-    res["sga_forward_fused_call"] = timed(lambda: lib.call(
+    res["sga_forward_call"] = timed(lambda: lib.call(
         "ganet_sga_forward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), out.data_ptr(),
-        mask.data_ptr(), N, C, D, H, W, st))
+        mask.data_ptr(), kp.data_ptr(), N, C, D, H, W, st))
+    res["sga_merge_argmax"] = res["sga_forward_call"] - sum(res[f"sga_scan_fwd_{n}"] for n in names)
+    npix = N * C * H * W
     for d in range(4):
-        res[f"sga_bwd_{names[d]}"] = timed(lambda d=d: lib.call(
-            "ganet_sga_backward_dir", x.data_ptr(), gs[d].data_ptr(), A[d].data_ptr(), mask.data_ptr(),
-            go.data_ptr(), gx.data_ptr(), gw[d].data_ptr(), N, C, D, H, W, d, 1 if d else 0, st))
+        res[f"sga_bwd_scan_{names[d]}"] = timed(lambda d=d: lib.call(
+            "ganet_sga_backward_scan", gs[d].data_ptr(), mask.data_ptr(), kp.data_ptr() + 2 * d * npix,
+            go.data_ptr(), G[d].data_ptr(), N, C, D, H, W, d, st))
+    res["sga_backward_call"] = timed(lambda: lib.call(
+        "ganet_sga_backward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), mask.data_ptr(),
+        kp.data_ptr(), go.data_ptr(), G.data_ptr(), gx.data_ptr(), *[g.data_ptr() for g in gw],
+        N, C, D, H, W, st))
+    res["sga_bwd_point"] = res["sga_backward_call"] - sum(res[f"sga_bwd_scan_{n}"] for n in names)
     res["lga_fwd_pass"] = timed(lambda: lib.call(
         "ganet_lga_forward", xl.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, RADIUS, st))
     res["lga_bwd_pass"] = timed(lambda: lib.call(
@@ -125,16 +134,19 @@ def stage_timings(inp, iters=5):
 
 def roofline_from_stages(stages):
     """Dominant kernel family = the one with the largest time share of a step.  `achieved` =
-    that family's algorithmic bytes (op-level figure of SURVEY 8d divided over its launches)
+    that family's algorithmic bytes (op-level figure of SURVEY 8d divided over its launches;
+    SGA backward = 3V+8G is split half to the four adjoint scans, half to the per-pixel kernel)
     / its average launch duration."""
     fam = {
         "sga_scan_fwd": ([k for k in stages if k.startswith("sga_scan_fwd_")], ALG_BYTES["sga_fwd"] / 4),
-        "sga_scan_bwd": ([k for k in stages if k.startswith("sga_bwd_")], ALG_BYTES["sga_bwd"] / 4),
+        "sga_bwd_scan": ([k for k in stages if k.startswith("sga_bwd_scan_")], ALG_BYTES["sga_bwd"] / 8),
+        "sga_bwd_point": (["sga_bwd_point"], ALG_BYTES["sga_bwd"] / 2),
         "lga_apply+filter_grad (bwd pass)": (["lga_bwd_pass"], ALG_BYTES["lga2_bwd"] / 2),
         "lga_apply (fwd pass)": (["lga_fwd_pass"], ALG_BYTES["lga2_fwd"] / 2),
     }
     # launches per step: 4 scans fwd, 4 bwd, 2 lga fwd passes, 2 lga bwd passes
-    mult = {"sga_scan_fwd": 1, "sga_scan_bwd": 1, "lga_apply+filter_grad (bwd pass)": 2, "lga_apply (fwd pass)": 2}
+    mult = {"sga_scan_fwd": 1, "sga_bwd_scan": 1, "sga_bwd_point": 1, "lga_apply+filter_grad (bwd pass)": 2,
+            "lga_apply (fwd pass)": 2}
     best, best_t = None, -1.0
     for name, (keys, _) in fam.items():
         t = sum(stages[k] for k in keys) * mult[name]

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -22,9 +22,10 @@ _PROTOS = {
     "ganet_is_simulator": [],
     "ganet_set_option": [ctypes.c_char_p, _I],
     "ganet_sga_scan_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "ganet_sga_forward": [_P] * 8 + [_I] * 5 + [_P],
-    "ganet_sga_backward_dir": [_P] * 7 + [_I] * 7 + [_P],
-    "ganet_sga_backward": [_P] * 13 + [_I] * 5 + [_P],
+    "ganet_sga_forward": [_P] * 9 + [_I] * 5 + [_P],
+    "ganet_sga_backward_scan": [_P] * 5 + [_I] * 6 + [_P],
+    "ganet_sga_backward_dir": [_P] * 9 + [_I] * 7 + [_P],
+    "ganet_sga_backward": [_P] * 15 + [_I] * 5 + [_P],
     "ganet_sga_forward_compat": [_P] * 8 + [_I] * 5 + [_P],
     "ganet_sga_backward_compat": [_P] * 15 + [_I] * 5 + [_P],
     "ganet_lga_forward": [_P] * 3 + [_I] * 5 + [_P],

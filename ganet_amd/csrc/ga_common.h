@@ -94,9 +94,19 @@ template <int CTRL> GA_DEV int dpp_i(int old, int src)
 template <int CTRL> GA_DEV int dpp_i(int old, int src) { return hipsim::update_dpp(old, src, CTRL); }
 #endif
 
+// full-permutation patterns (xor / mirror): every lane has an in-row source, so `old` is
+// irrelevant; the undef-old form lets the compiler fold the move into the consumer
+// (v_max_f32_dpp / v_add_f32_dpp) instead of emitting v_mov_b32_dpp + op.
+#if !defined(GA_HIPSIM) && !defined(GA_NO_DPP)
+template <int CTRL> GA_DEV int dpp_perm_i(int src) { return __builtin_amdgcn_mov_dpp(src, CTRL, 0xF, 0xF, true); }
+#else
+template <int CTRL> GA_DEV int dpp_perm_i(int src) { return dpp_i<CTRL>(src, src); }
+#endif
+
 GA_DEV int f2i(float f) { union { float f; int i; } u; u.f = f; return u.i; }
 GA_DEV float i2f(int i) { union { float f; int i; } u; u.i = i; return u.f; }
 template <int CTRL> GA_DEV float dpp_f(float old, float src) { return i2f(dpp_i<CTRL>(f2i(old), f2i(src))); }
+template <int CTRL> GA_DEV float dpp_perm_f(float src) { return i2f(dpp_perm_i<CTRL>(f2i(src))); }
 
 // ---- segment ops: a "segment" is GD consecutive lanes (GD in 1,2,4,8,16) that
 // together own one scanline; lg = lane % GD.
@@ -115,26 +125,26 @@ template <int GD> GA_DEV float seg_from_next(float old, float src, int lg)
 }
 template <int GD> GA_DEV float seg_allmax(float v)
 {
-  if (GD >= 2) v = fmaxf(v, dpp_f<DPP_QP_XOR1>(v, v));
-  if (GD >= 4) v = fmaxf(v, dpp_f<DPP_QP_XOR2>(v, v));
-  if (GD >= 8) v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v, v));
-  if (GD >= 16) v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v, v));
+  if (GD >= 2) v = fmaxf(v, dpp_perm_f<DPP_QP_XOR1>(v));
+  if (GD >= 4) v = fmaxf(v, dpp_perm_f<DPP_QP_XOR2>(v));
+  if (GD >= 8) v = fmaxf(v, dpp_perm_f<DPP_ROW_HALF_MIRROR>(v));
+  if (GD >= 16) v = fmaxf(v, dpp_perm_f<DPP_ROW_MIRROR>(v));
   return v;
 }
 template <int GD> GA_DEV float seg_allsum(float v)
 {
-  if (GD >= 2) v += dpp_f<DPP_QP_XOR1>(v, v);
-  if (GD >= 4) v += dpp_f<DPP_QP_XOR2>(v, v);
-  if (GD >= 8) v += dpp_f<DPP_ROW_HALF_MIRROR>(v, v);
-  if (GD >= 16) v += dpp_f<DPP_ROW_MIRROR>(v, v);
+  if (GD >= 2) v += dpp_perm_f<DPP_QP_XOR1>(v);
+  if (GD >= 4) v += dpp_perm_f<DPP_QP_XOR2>(v);
+  if (GD >= 8) v += dpp_perm_f<DPP_ROW_HALF_MIRROR>(v);
+  if (GD >= 16) v += dpp_perm_f<DPP_ROW_MIRROR>(v);
   return v;
 }
 // (max value, smallest index attaining it) over the segment: the reference's
 // strict-'<' first-argmax (GANet_kernel.cu:60-62, 122-123)
 template <int CTRL> GA_DEV void argmax_merge(float &v, int &k)
 {
-  const float ov = dpp_f<CTRL>(v, v);
-  const int ok = dpp_i<CTRL>(k, k);
+  const float ov = dpp_perm_f<CTRL>(v);
+  const int ok = dpp_perm_i<CTRL>(k);
   const bool take = (ov > v) || (ov == v && ok < k);
   v = take ? ov : v;
   k = take ? ok : k;
@@ -145,6 +155,16 @@ template <int GD> GA_DEV void seg_argmax(float &v, int &k)
   if (GD >= 4) argmax_merge<DPP_QP_XOR2>(v, k);
   if (GD >= 8) argmax_merge<DPP_ROW_HALF_MIRROR>(v, k);
   if (GD >= 16) argmax_merge<DPP_ROW_MIRROR>(v, k);
+}
+
+template <int GD> GA_DEV int seg_allmin_i(int v)
+{
+  int o;
+  if (GD >= 2) { o = dpp_perm_i<DPP_QP_XOR1>(v); v = o < v ? o : v; }
+  if (GD >= 4) { o = dpp_perm_i<DPP_QP_XOR2>(v); v = o < v ? o : v; }
+  if (GD >= 8) { o = dpp_perm_i<DPP_ROW_HALF_MIRROR>(v); v = o < v ? o : v; }
+  if (GD >= 16) { o = dpp_perm_i<DPP_ROW_MIRROR>(v); v = o < v ? o : v; }
+  return v;
 }
 
 // ---- whole-wave (64-lane) ops for kernels where ONE scanline owns the wavefront -------

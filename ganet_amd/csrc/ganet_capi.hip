@@ -134,11 +134,8 @@ int get_pool(SidePool **out)
 
 constexpr int fwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
 constexpr int fwd_nv(int dpl) { return dpl <= 5 ? 2 : 1; }
-constexpr int bwd_sb(int dpl) { return dpl <= 3 ? 4 : dpl <= 5 ? 2 : 1; }
-constexpr int bwd_nv(int) { return 1; }
-// float4 backward keeps 2 x (4 float4 + mask) per owned disparity in VGPRs: beyond
-// DPL = 5 it spills, so wider lanes use the element-strided traversal instead.
-constexpr bool bwd_rowvec_ok(int dpl) { return dpl <= 5; }
+constexpr int bwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
+constexpr int bwd_nv(int dpl) { return dpl <= 5 ? 2 : 1; }
 
 bool pick_pair(int D, int want_gd, int *gd, int *dpl)
 {
@@ -198,28 +195,39 @@ int launch_scan_fwd(const float *x, const float *g, float *A, int S, int D, int 
 }
 
 template <int GD, int DPL>
-int launch_scan_bwd(const float *x, const float *g, const float *A, const uint8_t *mask,
-                    const float *gout, float *gx, float *gw, int S, int D, int H, int W, int dir,
-                    int accumulate, hipStream_t st)
+int launch_scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout,
+                     float *G, int S, int D, int H, int W, int dir, hipStream_t st)
 {
   const Options &o = opts();
   ScanGeom geo = make_geom(S, D, H, W, dir, true);
-  const bool rowvec = bwd_rowvec_ok(DPL) && dir >= 2 && (W % 4 == 0) && aligned16(x) &&
-                      aligned16(g) && aligned16(A) && aligned16(gout) && aligned16(gx) && aligned16(gw) && (((uintptr_t)mask & 3) == 0);
+  const bool rowvec = dir >= 2 && (W % 4 == 0) && aligned16(g) && aligned16(gout) && aligned16(G) &&
+                      (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
   int block = dir < 2 ? o.block_v : o.block_h;
   if (block < 64 || block > 256 || block % 64) block = 64;
   const int lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
   if (rowvec) {
-    // backward of `right` (2) visits w descending, of `left` (3) ascending
-    if constexpr (bwd_rowvec_ok(DPL))
-      GA_LAUNCH((sga_bwd_rowvec<GD, DPL, bwd_nv(DPL)>), dim3(grid), dim3(block), st, x, g, A, mask,
-                gout, gx, gw, geo, dir, accumulate, dir == 2 ? 1 : 0);
+    // the adjoint of `right` (2) visits w descending, of `left` (3) ascending
+    GA_LAUNCH((sga_bwdg_rowvec<GD, DPL, bwd_nv(DPL)>), dim3(grid), dim3(block), st, g, mask, kp, gout,
+              G, geo, dir, dir == 2 ? 1 : 0);
   } else {
-    GA_LAUNCH((sga_bwd_strided<GD, DPL, bwd_sb(DPL)>), dim3(grid), dim3(block), st, x, g, A, mask,
-              gout, gx, gw, geo, dir, accumulate);
+    GA_LAUNCH((sga_bwdg_strided<GD, DPL, bwd_sb(DPL), uint8_t>), dim3(grid), dim3(block), st, g, mask,
+              kp, gout, G, geo, dir);
   }
-  return check_launch("sga scan backward");
+  return check_launch("sga adjoint scan");
+}
+
+// float-valued mask (reference buffer contract): element-strided traversal, GD = 16 family
+template <int DPL>
+int launch_scan_bwdg_f32mask(const float *g, const float *mask, const uint16_t *kp, const float *gout,
+                             float *G, int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  ScanGeom geo = make_geom(S, D, H, W, dir, true);
+  const int block = 64, lpb = block / 16;
+  const int grid = (geo.total_lines + lpb - 1) / lpb;
+  GA_LAUNCH((sga_bwdg_strided<16, DPL, bwd_sb(DPL), float>), dim3(grid), dim3(block), st, g, mask, kp,
+            gout, G, geo, dir);
+  return check_launch("sga adjoint scan (f32 mask)");
 }
 
 int check_dims5(const char *who, int N, int C, int D, int H, int W)
@@ -232,52 +240,46 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
 }
 
 // ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
-constexpr int ROW_SBH = 16;
-constexpr size_t ROW_SMEM_MAX = 60 * 1024;
+// rows per wavefront (LN) x positions per staged batch (SBH): LDS per wave bounds residency
+constexpr int ROW_SBH_F = 16, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: 2 tiles per row  (10.7 KB per row at D=65)
+constexpr size_t ROW_SMEM_MAX = 64 * 1024;
 
-size_t row_smem_fwd(int D) { return sizeof(float) * ((size_t)2 * D * RowCfg<ROW_SBH>::RS + 5 * ROW_SBH); }
-size_t row_smem_bwd(int D)
+size_t row_smem_fwd(int D)
 {
-  const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH>::PP + 1) + 3) & ~(size_t)3;
-  return sizeof(float) * ((size_t)4 * D * RowCfg<ROW_SBH>::RS + mask_words + 10 * ROW_SBH);
+  return sizeof(float) * ROW_LN_F * ((size_t)2 * D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
 }
-
 bool rowwave_ok(int D, int W, int dir, size_t smem)
 {
-  return opts().rowwave && dir >= 2 && W % 4 == 0 && D <= 256 && smem <= ROW_SMEM_MAX;
+  return opts().rowwave && dir >= 2 && W % 4 == 0 && D <= 16 * 13 && smem <= ROW_SMEM_MAX;
+}
+
+// disparities per lane of the single DPP row that carries the recurrence (D <= 16 * DPL)
+#define GA_ROW_DPLS(X) X(1) X(2) X(3) X(5) X(9) X(13)
+
+int row_dpl(int D)
+{
+  int best = 0;
+#define X(P) if (best == 0 && 16 * (P) >= D) best = (P);
+  GA_ROW_DPLS(X)
+#undef X
+  return best;
 }
 
 int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
 {
   RowGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  const int dpl = (D + 63) / 64, desc = dir == 3 ? 1 : 0;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
+  const int dpl = row_dpl(D);
   const size_t smem = row_smem_fwd(D);
-  const dim3 grid(S * H), block(64);
-  switch (dpl) {
-    case 1: GA_LAUNCH_SMEM((sga_row_fwd<1, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
-    case 2: GA_LAUNCH_SMEM((sga_row_fwd<2, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
-    case 3: GA_LAUNCH_SMEM((sga_row_fwd<3, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
-    default: GA_LAUNCH_SMEM((sga_row_fwd<4, ROW_SBH>), grid, block, smem, st, x, g, A, geo, desc); break;
+  const dim3 grid((S * H + ROW_LN_F - 1) / ROW_LN_F), block(64);
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 3) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true>), grid, block, smem, st, x, g, A, geo);  \
+    else GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false>), grid, block, smem, st, x, g, A, geo);          \
   }
+  GA_ROW_DPLS(X)
+#undef X
   return check_launch("sga row forward");
-}
-
-int row_bwd(const float *x, const float *g, const float *A, const uint8_t *mask, const float *gout,
-            float *gx, float *gw, int S, int D, int H, int W, int dir, int accumulate, hipStream_t st)
-{
-  RowGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  const int dpl = (D + 63) / 64, desc = dir == 2 ? 1 : 0;   // backward of `right` walks w down
-  const size_t smem = row_smem_bwd(D);
-  const dim3 grid(S * H), block(64);
-  switch (dpl) {
-    case 1: GA_LAUNCH_SMEM((sga_row_bwd<1, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
-    case 2: GA_LAUNCH_SMEM((sga_row_bwd<2, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
-    case 3: GA_LAUNCH_SMEM((sga_row_bwd<3, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
-    default: GA_LAUNCH_SMEM((sga_row_bwd<4, ROW_SBH>), grid, block, smem, st, x, g, A, mask, gout, gx, gw, geo, dir, accumulate, desc); break;
-  }
-  return check_launch("sga row backward");
 }
 
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
@@ -295,22 +297,50 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
   return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for GD=%d DPL=%d", gd, dpl);
 }
 
-int scan_bwd(const float *x, const float *g, const float *A, const uint8_t *mask, const float *gout,
-             float *gx, float *gw, int N, int C, int D, int H, int W, int dir, int accumulate,
-             hipStream_t st)
+int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
+              int N, int C, int D, int H, int W, int dir, hipStream_t st)
 {
-  if (rowwave_ok(D, W, dir, row_smem_bwd(D)) && aligned16(x) && aligned16(g) && aligned16(A) &&
-      aligned16(gout) && aligned16(gx) && aligned16(gw) && (((uintptr_t)mask & 3) == 0))
-    return row_bwd(x, g, A, mask, gout, gx, gw, N * C, D, H, W, dir, accumulate, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
-#define X(G, P)                  \
-  if (gd == (G) && dpl == (P))   \
-    return launch_scan_bwd<G, P>(x, g, A, mask, gout, gx, gw, N * C, D, H, W, dir, accumulate, st);
+#define X(G_, P) \
+  if (gd == (G_) && dpl == (P)) return launch_scan_bwdg<G_, P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   GA_SGA_PAIRS(X)
 #undef X
   return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for GD=%d DPL=%d", gd, dpl);
+}
+
+int scan_bwdg_f32mask(const float *g, const float *mask, const uint16_t *kp, const float *gout, float *G,
+                      int N, int C, int D, int H, int W, int dir, hipStream_t st)
+{
+  int gd, dpl;
+  if (!pick_pair(D, 16, &gd, &dpl))
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+#define X(G_, P) \
+  if ((G_) == 16 && dpl == (P)) return launch_scan_bwdg_f32mask<P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
+  GA_SGA_PAIRS(X)
+#undef X
+  return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for DPL=%d", dpl);
+}
+
+int px_grid(i64 npix)
+{
+  i64 g = (npix + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// per-pixel gradients for `ndir` (1 or 4) directions
+int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, int C, int D, int H, int W,
+              int accumulate, hipStream_t st)
+{
+  const i64 npix = (i64)N * C * H * W;
+  if (ndir == 4)
+    GA_LAUNCH((sga_bwd_point<4>), dim3(px_grid(npix)), dim3(256), st, x, gx, pa, D, H, W, npix, accumulate);
+  else
+    GA_LAUNCH((sga_bwd_point<1>), dim3(px_grid(npix)), dim3(256), st, x, gx, pa, D, H, W, npix, accumulate);
+  return check_launch("sga per-pixel gradients");
 }
 
 int ew_grid(i64 n)
@@ -410,13 +440,15 @@ GA_EXPORT int ganet_sga_scan_forward(const float *x, const float *g, float *A, i
 }
 
 GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
-                                const float *g3, float *A_ws, float *out, uint8_t *mask, int N,
-                                int C, int D, int H, int W, void *stream)
+                                const float *g3, float *A_ws, float *out, uint8_t *mask,
+                                uint16_t *kp, int N, int C, int D, int H, int W, void *stream)
 {
-  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out || !mask)
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out || !mask || !kp)
     return fail(GANET_E_INVALID, "ganet_sga_forward: null pointer");
   GA_TRY(check_dims5("ganet_sga_forward", N, C, D, H, W));
+  if (D > 65535) return fail(GANET_E_UNSUPPORTED, "ganet_sga_forward: D > 65535");
   const i64 n = (i64)N * C * D * H * W;
+  const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   if (opts().streams) {
@@ -433,42 +465,60 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   } else {
     for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   }
-  GA_LAUNCH((sga_merge4<uint8_t>), dim3(ew_grid(n)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
-            A_ws + 3 * n, out, mask, n);
+  GA_LAUNCH((sga_merge_px<uint8_t>), dim3(px_grid(npix)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
+            A_ws + 3 * n, out, mask, kp, D, (i64)H * W, npix);
   return check_launch("sga merge");
 }
 
-GA_EXPORT int ganet_sga_backward_dir(const float *x, const float *g, const float *A,
-                                     const uint8_t *mask, const float *grad_out, float *grad_x,
-                                     float *gw, int N, int C, int D, int H, int W, int dir,
-                                     int accumulate, void *stream)
+GA_EXPORT int ganet_sga_backward_scan(const float *g, const uint8_t *mask, const uint16_t *kp_dir,
+                                      const float *grad_out, float *G, int N, int C, int D, int H,
+                                      int W, int dir, void *stream)
 {
-  if (!x || !g || !A || !mask || !grad_out || !grad_x || !gw)
+  if (!g || !mask || !kp_dir || !grad_out || !G)
+    return fail(GANET_E_INVALID, "ganet_sga_backward_scan: null pointer");
+  if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_backward_scan: dir %d", dir);
+  GA_TRY(check_dims5("ganet_sga_backward_scan", N, C, D, H, W));
+  return scan_bwdg(g, mask, kp_dir, grad_out, G, N, C, D, H, W, dir, (hipStream_t)stream);
+}
+
+GA_EXPORT int ganet_sga_backward_dir(const float *x, const float *g, const float *A,
+                                     const uint8_t *mask, const uint16_t *kp_dir,
+                                     const float *grad_out, float *G_ws, float *grad_x, float *gw,
+                                     int N, int C, int D, int H, int W, int dir, int accumulate,
+                                     void *stream)
+{
+  if (!x || !g || !A || !mask || !kp_dir || !grad_out || !G_ws || !grad_x || !gw)
     return fail(GANET_E_INVALID, "ganet_sga_backward_dir: null pointer");
   if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_backward_dir: dir %d", dir);
   GA_TRY(check_dims5("ganet_sga_backward_dir", N, C, D, H, W));
-  return scan_bwd(x, g, A, mask, grad_out, grad_x, gw, N, C, D, H, W, dir, accumulate ? 1 : 0,
-                  (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  GA_TRY(scan_bwdg(g, mask, kp_dir, grad_out, G_ws, N, C, D, H, W, dir, st));
+  PointArgs pa = {};
+  pa.G[0] = G_ws; pa.A[0] = A; pa.g[0] = g; pa.gw[0] = gw; pa.dir[0] = dir;
+  return bwd_point(x, grad_x, pa, 1, N, C, D, H, W, accumulate ? 1 : 0, st);
 }
 
 GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
                                  const float *g3, const float *A_ws, const uint8_t *mask,
-                                 const float *grad_out, float *grad_x, float *gw0, float *gw1,
-                                 float *gw2, float *gw3, int N, int C, int D, int H, int W,
-                                 void *stream)
+                                 const uint16_t *kp, const float *grad_out, float *G_ws,
+                                 float *grad_x, float *gw0, float *gw1, float *gw2, float *gw3,
+                                 int N, int C, int D, int H, int W, void *stream)
 {
-  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !mask || !grad_out || !grad_x || !gw0 || !gw1 ||
-      !gw2 || !gw3)
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !mask || !kp || !grad_out || !G_ws || !grad_x ||
+      !gw0 || !gw1 || !gw2 || !gw3)
     return fail(GANET_E_INVALID, "ganet_sga_backward: null pointer");
   GA_TRY(check_dims5("ganet_sga_backward", N, C, D, H, W));
   const i64 n = (i64)N * C * D * H * W;
+  const i64 npix = (i64)N * C * H * W;
+  hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   float *gws[4] = {gw0, gw1, gw2, gw3};
-  // grad_x is produced by direction 0 and accumulated by 1..3 on one stream (ordered)
-  for (int d = 0; d < 4; d++)
-    GA_TRY(scan_bwd(x, gs[d], A_ws + d * n, mask, grad_out, grad_x, gws[d], N, C, D, H, W, d,
-                    d > 0, (hipStream_t)stream));
-  return GANET_OK;
+  PointArgs pa = {};
+  for (int d = 0; d < 4; d++) {
+    GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st));
+    pa.G[d] = G_ws + d * n; pa.A[d] = A_ws + d * n; pa.g[d] = gs[d]; pa.gw[d] = gws[d]; pa.dir[d] = d;
+  }
+  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, st);
 }
 
 GA_EXPORT int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1,
@@ -499,23 +549,29 @@ GA_EXPORT int ganet_sga_backward_compat(const float *x, const float *g0, const f
                                         float *gw0, float *gw1, float *gw2, float *gw3, int N,
                                         int C, int D, int H, int W, void *stream)
 {
-  (void)max_idx;
-  if (!x || !g0 || !g1 || !g2 || !g3 || !temp_out || !mask_f32 || !grad_out || !temp_grad ||
-      !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
+  if (!x || !g0 || !g1 || !g2 || !g3 || !temp_out || !mask_f32 || !max_idx || !grad_out ||
+      !temp_grad || !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
     return fail(GANET_E_INVALID, "ganet_sga_backward_compat: null pointer");
   GA_TRY(check_dims5("ganet_sga_backward_compat", N, C, D, H, W));
-  const i64 n = (i64)N * C * D * H * W;
+  if (D > 65535) return fail(GANET_E_UNSUPPORTED, "ganet_sga_backward_compat: D > 65535");
+  const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
-  uint8_t *mask8 = reinterpret_cast<uint8_t *>(temp_grad);   // scratch: n bytes of 4n
-  GA_LAUNCH(mask_f32_to_u8, dim3(ew_grid(n)), dim3(256), st, mask_f32, mask8, n);
-  GA_TRY(check_launch("mask convert"));
+  // scratch roles as in the reference: temp_out = A_dir, temp_grad = adjoint volume,
+  // max_idx = first-argmax per pixel (stored as uint16 in the first half of the buffer)
+  uint16_t *kp = reinterpret_cast<uint16_t *>(max_idx);
   const float *gs[4] = {g0, g1, g2, g3};
   float *gws[4] = {gw0, gw1, gw2, gw3};
   const int order[4] = {3, 0, 1, 2};   // GANet_kernel.cu:1040-1128
   for (int i = 0; i < 4; i++) {
     const int d = order[i];
     if (d != 3) GA_TRY(scan_fwd(x, gs[d], temp_out, N, C, D, H, W, d, st));
-    GA_TRY(scan_bwd(x, gs[d], temp_out, mask8, grad_out, grad_x, gws[d], N, C, D, H, W, d, 1, st));
+    GA_LAUNCH(sga_argmax_px, dim3(px_grid(npix)), dim3(256), st, temp_out, kp, D, (i64)H * W, npix);
+    GA_TRY(check_launch("sga argmax"));
+    GA_TRY(scan_bwdg_f32mask(gs[d], mask_f32, kp, grad_out, temp_grad, N, C, D, H, W, d, st));
+    PointArgs pa = {};
+    pa.G[0] = temp_grad; pa.A[0] = temp_out; pa.g[0] = gs[d]; pa.gw[0] = gws[d]; pa.dir[0] = d;
+    // gradInput is accumulated into (caller zero-fills); gw is written (each pixel once per direction)
+    GA_TRY(bwd_point(x, grad_x, pa, 1, N, C, D, H, W, 1, st));
   }
   return GANET_OK;
 }

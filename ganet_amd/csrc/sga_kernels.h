@@ -19,11 +19,11 @@
 //    elements (lanes of GD-lane segments side by side along W -> coalesced);
 //    horizontal scans read float4 along W (4 positions per load) so every 16-byte
 //    piece of a cache line is fetched by exactly one lane.
-//  * Backward is ONE pass per direction: the reverse-scan adjoint, the masked
-//    gradOutput gather, the first-argmax routing and all five guidance-weight
-//    reductions happen in the same sweep (the reference uses memset +
-//    get_temp_grad + MaxDepth + data_backward + weight_backward = 5 launches and
-//    re-reads everything; its weight kernel does a global RMW per disparity).
+//  * Backward = four light adjoint scans (G only) + ONE per-pixel kernel that produces
+//    gradX and all guidance-weight gradients for the four directions together (see the
+//    "Backward" banner below).  The reference uses, per direction, memset + get_temp_grad
+//    + MaxDepth + data_backward + weight_backward (global RMW per disparity) and three
+//    recomputed forward scans.
 //
 // Numerics: forward uses the reference's exact fma order
 //   ((((x*w0) + P1*w1) + P2*w2) + P3*w3) + P4*w4
@@ -232,108 +232,72 @@ sga_fwd_rowvec(const float *__restrict__ x, const float *__restrict__ g, float *
 #undef GA_COMPUTE_BATCH
 }
 
-// ---- backward, one visited position ---------------------------------------------
-// Visit order is the REVERSE of the forward scan.  "nx" = the position visited just
-// before (forward position p+1), "pv" = the position visited next (forward p-1).
-struct BwdCarry {
-  float wn[5];   // guidance at p+1
-  float SGn;     // sum_d G[p+1][d]
-  int kp;        // first-argmax_d A[p][.]   (routing target at this visit)
-};
+// =====================================================================================
+// Backward.  Split in two (measured: the single-sweep version spent ~200 VALU/position on
+// work that is NOT part of the recurrence and ran at 0.26-0.52 ms per direction):
+//
+//   1. sga_bwdg_*: the reverse-scan adjoint ONLY.  G[p][d] = [mask==dir]*gradOut
+//        + G[p+1][d]*w1[p+1] + G[p+1][d+1]*w2[p+1] + G[p+1][d-1]*w3[p+1]
+//        + [d == k_p] * w4[p+1] * sum_d' G[p+1][d'],   k_p = first-argmax_d A[p][.]
+//      (GANet_kernel.cu:144-181 and mirrors).  k_p comes from the forward merge kernel
+//      (uint16 per pixel and direction), so the scan touches gradOut, mask, G only.
+//   2. sga_bwd_point: everything else is independent per pixel -- one lane per pixel loops
+//      over d for ALL directions at once: input gradient (read x once, write gradX once,
+//      no read-modify-write per direction) and the five guidance-weight sums
+//      (GANet_kernel.cu:164-207, 226-272).  No cross-lane traffic at all.
+// HBM traffic: 4 x (1.25 V in + 1 V out) + (1 + 4 + 4) V in + 1 V out = 19 V, the same as
+// four fused sweeps, with the serial path ~5x shorter.
+// =====================================================================================
 
-template <int GD, int DPL>
-GA_DEV void bwd_step(const float (&go)[DPL], const uint8_t (&mk)[DPL], const float (&xs)[DPL],
-                     const float (&Am)[DPL], const float (&w)[5], float (&Gn)[DPL], BwdCarry &cy,
-                     float (&gxo)[DPL], float (&gwo)[5], bool has_nx, bool has_pv,
-                     const LaneCtx &c, int D, int dir)
+// ---- reverse-scan adjoint, one visited position -------------------------------------
+// Gn: G at the previously visited position (forward p+1); wn its guidance; sgn = sum_d Gn.
+template <int GD, int DPL, typename MaskT>
+GA_DEV void bwdg_step(const float (&go)[DPL], const MaskT (&mk)[DPL], float (&Gn)[DPL],
+                      float (&wn)[5], float &sgn, const float (&w)[5], int kp, bool has_nx,
+                      const LaneCtx &c, int D, int dir)
 {
   float G[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; i++) G[i] = (c.d0 + i < D && (int)mk[i] == dir) ? go[i] : 0.f;
   if (has_nx) {
-    const float lo = seg_from_prev<GD>(0.f, Gn[DPL - 1], c.lg);   // G[p+1][d0-1] | 0
-    const float hi = seg_from_next<GD>(0.f, Gn[0], c.lg);         // G[p+1][d0+DPL] | 0
-    const float t4 = cy.wn[4] * cy.SGn;
+    const float lo = seg_from_prev<GD>(0.f, Gn[DPL - 1], c.lg);
+    const float hi = seg_from_next<GD>(0.f, Gn[0], c.lg);
+    const float t4 = wn[4] * sgn;
 #pragma unroll
     for (int i = 0; i < DPL; i++) {
       const float up = i < DPL - 1 ? Gn[i + 1] : hi;
       const float dn = i > 0 ? Gn[i - 1] : lo;
       float t = G[i];
-      t = fmaf(Gn[i], cy.wn[1], t);
-      t = fmaf(up, cy.wn[2], t);
-      t = fmaf(dn, cy.wn[3], t);
-      if (c.d0 + i == cy.kp) t += t4;
+      t = fmaf(Gn[i], wn[1], t);
+      t = fmaf(up, wn[2], t);
+      t = fmaf(dn, wn[3], t);
+      if (c.d0 + i == kp) t += t4;
       G[i] = (c.d0 + i < D) ? t : 0.f;
     }
   }
-  // input gradient contribution of this direction (A.2 incl. the d=0 / d=D-1 terms)
+  float sg = 0.f;
 #pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    float r = G[i] * w[0];
-    if (c.d0 + i == 0) r = fmaf(G[i], w[2], r);
-    if (c.d0 + i == D - 1) r = fmaf(G[i], w[3], r);
-    gxo[i] = r;
-  }
-  // guidance-weight reductions
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, sg = 0.f, mv = -INFINITY;
-  int mk_idx = 0x7fffffff;
+  for (int i = 0; i < DPL; i++) { Gn[i] = G[i]; sg += G[i]; }
 #pragma unroll
-  for (int i = 0; i < DPL; i++) { s0 = fmaf(G[i], xs[i], s0); sg += G[i]; }
-  if (has_pv) {
-    const float alo = seg_from_prev<GD>(0.f, Am[DPL - 1], c.lg);
-    const float ahi = seg_from_next<GD>(0.f, Am[0], c.lg);
-#pragma unroll
-    for (int i = 0; i < DPL; i++) {
-      const int d = c.d0 + i;
-      const float a2 = d >= 1 ? (i > 0 ? Am[i - 1] : alo) : xs[i];
-      const float a3 = d + 1 < D ? (i < DPL - 1 ? Am[i + 1] : ahi) : xs[i];
-      s1 = fmaf(G[i], Am[i], s1);
-      s2 = fmaf(G[i], a2, s2);
-      s3 = fmaf(G[i], a3, s3);
-      if (d < D && (Am[i] > mv)) { mv = Am[i]; mk_idx = d; }
-    }
-    seg_argmax<GD>(mv, mk_idx);
-  }
-  s0 = seg_allsum<GD>(s0);
-  sg = seg_allsum<GD>(sg);
-  if (has_pv) {
-    s1 = seg_allsum<GD>(s1);
-    s2 = seg_allsum<GD>(s2);
-    s3 = seg_allsum<GD>(s3);
-  }
-  gwo[0] = s0;
-  gwo[1] = has_pv ? s1 : 0.f;
-  gwo[2] = has_pv ? s2 : 0.f;
-  gwo[3] = has_pv ? s3 : 0.f;
-  gwo[4] = has_pv ? sg * mv : 0.f;
-  // carry to the next visit (forward position p-1)
-#pragma unroll
-  for (int i = 0; i < DPL; i++) Gn[i] = G[i];
-#pragma unroll
-  for (int t = 0; t < 5; t++) cy.wn[t] = w[t];
-  cy.SGn = sg;
-  cy.kp = mk_idx;
+  for (int t = 0; t < 5; t++) wn[t] = w[t];
+  sgn = seg_allsum<GD>(sg);
 }
 
-// ---- backward scan, element-strided traversal ------------------------------------
-// geo is in VISIT order (start = forward position L-1, step_stride = -forward step).
-// A is this direction's forward volume.  gradX: accumulate ? += : =.   gw: plain store
-// (every guidance pixel is produced exactly once per direction).
-template <int GD, int DPL, int SB>
+// ---- adjoint scan, element-strided traversal (geo in VISIT order = reverse of forward) ----
+template <int GD, int DPL, int SB, typename MaskT>
 __global__ void __launch_bounds__(256)
-sga_bwd_strided(const float *__restrict__ x, const float *__restrict__ g,
-                const float *__restrict__ A, const uint8_t *__restrict__ mask,
-                const float *__restrict__ gout, float *__restrict__ gradX, float *__restrict__ gw,
-                ScanGeom geo, int dir, int accumulate)
+sga_bwdg_strided(const float *__restrict__ g, const MaskT *__restrict__ mask,
+                 const uint16_t *__restrict__ kp, const float *__restrict__ gout,
+                 float *__restrict__ G, ScanGeom geo, int dir)
 {
   const LaneCtx c = make_ctx<GD, DPL>(geo);
   const i64 lineoff = geo.start + (i64)c.q * geo.line_stride;
   const i64 vbase = (i64)c.s * geo.D * geo.HW + lineoff;
-  const float *xb = x + vbase, *Ab = A + vbase, *gob = gout + vbase;
-  const uint8_t *mb = mask + vbase;
-  float *gxb = gradX + vbase;
+  const float *gob = gout + vbase;
+  const MaskT *mb = mask + vbase;
+  float *Gb = G + vbase;
   const float *gb = g + (i64)c.s * 5 * geo.HW + lineoff;
-  float *gwb = gw + (i64)c.s * 5 * geo.HW + lineoff;
+  const uint16_t *kb = kp + (i64)c.s * geo.HW + lineoff;
   i64 eoff[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; i++) {
@@ -342,45 +306,36 @@ sga_bwd_strided(const float *__restrict__ x, const float *__restrict__ g,
   }
   const int L = geo.L;
   const int nb = (L + SB - 1) / SB;
-  float gobuf[2][SB][DPL], xbuf[2][SB][DPL], abuf[2][SB][DPL], wbuf[2][SB][5], gxbuf[2][SB][DPL];
-  uint8_t mbuf[2][SB][DPL];
-  float Gn[DPL];
-  BwdCarry cy;
+  float gobuf[2][SB][DPL], wbuf[2][SB][5];
+  MaskT mbuf[2][SB][DPL];
+  int kbuf[2][SB];
+  float Gn[DPL], wn[5], sgn = 0.f;
 #pragma unroll
   for (int i = 0; i < DPL; i++) Gn[i] = 0.f;
 #pragma unroll
-  for (int t = 0; t < 5; t++) cy.wn[t] = 0.f;
-  cy.SGn = 0.f;
-  cy.kp = -1;
+  for (int t = 0; t < 5; t++) wn[t] = 0.f;
 
 #define GA_LOAD_BATCH(B, BUF)                                                   \
   _Pragma("unroll") for (int j = 0; j < SB; j++) {                              \
     int v = (B) * SB + j;                                                       \
     v = v < L ? v : L - 1;                                                      \
     const i64 po = (i64)v * geo.step_stride;                                    \
-    const i64 pa = (i64)(v + 1 < L ? v + 1 : v) * geo.step_stride;              \
     _Pragma("unroll") for (int i = 0; i < DPL; i++) {                           \
       gobuf[BUF][j][i] = gob[eoff[i] + po];                                     \
       mbuf[BUF][j][i] = mb[eoff[i] + po];                                       \
-      xbuf[BUF][j][i] = xb[eoff[i] + po];                                       \
-      abuf[BUF][j][i] = Ab[eoff[i] + pa];                                       \
-      gxbuf[BUF][j][i] = accumulate ? gxb[eoff[i] + po] : 0.f;                  \
     }                                                                           \
     _Pragma("unroll") for (int t = 0; t < 5; t++) wbuf[BUF][j][t] = gb[t * geo.HW + po]; \
+    kbuf[BUF][j] = (int)kb[po];                                                 \
   }
 #define GA_COMPUTE_BATCH(B, BUF)                                                \
   _Pragma("unroll") for (int j = 0; j < SB; j++) {                              \
     const int v = (B) * SB + j;                                                 \
     if (v < L) {                                                                \
-      float gxo[DPL], gwo[5];                                                   \
-      bwd_step<GD, DPL>(gobuf[BUF][j], mbuf[BUF][j], xbuf[BUF][j], abuf[BUF][j], wbuf[BUF][j], \
-                        Gn, cy, gxo, gwo, v > 0, v + 1 < L, c, geo.D, dir);     \
+      bwdg_step<GD, DPL, MaskT>(gobuf[BUF][j], mbuf[BUF][j], Gn, wn, sgn, wbuf[BUF][j], kbuf[BUF][j], \
+                         v > 0, c, geo.D, dir);                                 \
       const i64 po = (i64)v * geo.step_stride;                                  \
       _Pragma("unroll") for (int i = 0; i < DPL; i++)                           \
-        if (c.line_ok && c.d0 + i < geo.D) gxb[eoff[i] + po] = gxbuf[BUF][j][i] + gxo[i]; \
-      if (c.line_ok && c.lg == 0) {                                             \
-        _Pragma("unroll") for (int t = 0; t < 5; t++) gwb[t * geo.HW + po] = gwo[t]; \
-      }                                                                         \
+        if (c.line_ok && c.d0 + i < geo.D) Gb[eoff[i] + po] = Gn[i];            \
     }                                                                           \
   }
 
@@ -396,27 +351,21 @@ sga_bwd_strided(const float *__restrict__ x, const float *__restrict__ g,
 #undef GA_COMPUTE_BATCH
 }
 
-// ---- backward scan along W with float4 traffic (right / left) ----------------------
-// desc: VISIT order runs w = W-1 .. 0 (i.e. the backward pass of `right`); otherwise
-// w = 0 .. W-1 (backward pass of `left`).  Requires W % 4 == 0, 16-byte aligned bases.
-// The forward volume at the NEXT visited position is the next component in visit
-// order; for the last component of a float4 it is the first of the following float4,
-// which is already resident in the other (prefetched) buffer.
+// ---- adjoint scan along W with float4 traffic.  desc: visit w = W-1 .. 0 ----------------
 template <int GD, int DPL, int NV>
 __global__ void __launch_bounds__(256)
-sga_bwd_rowvec(const float *__restrict__ x, const float *__restrict__ g,
-               const float *__restrict__ A, const uint8_t *__restrict__ mask,
-               const float *__restrict__ gout, float *__restrict__ gradX, float *__restrict__ gw,
-               ScanGeom geo, int dir, int accumulate, int desc)
+sga_bwdg_rowvec(const float *__restrict__ g, const uint8_t *__restrict__ mask,
+                const uint16_t *__restrict__ kp, const float *__restrict__ gout,
+                float *__restrict__ G, ScanGeom geo, int dir, int desc)
 {
   const LaneCtx c = make_ctx<GD, DPL>(geo);
   const i64 rowoff = (i64)c.q * geo.W;
   const i64 vbase = (i64)c.s * geo.D * geo.HW + rowoff;
-  const float *xb = x + vbase, *Ab = A + vbase, *gob = gout + vbase;
+  const float *gob = gout + vbase;
   const uint8_t *mb = mask + vbase;
-  float *gxb = gradX + vbase;
+  float *Gb = G + vbase;
   const float *gb = g + (i64)c.s * 5 * geo.HW + rowoff;
-  float *gwb = gw + (i64)c.s * 5 * geo.HW + rowoff;
+  const uint16_t *kb = kp + (i64)c.s * geo.HW + rowoff;
   i64 eoff[DPL];
 #pragma unroll
   for (int i = 0; i < DPL; i++) {
@@ -425,16 +374,14 @@ sga_bwd_rowvec(const float *__restrict__ x, const float *__restrict__ g,
   }
   const int NF = geo.W >> 2;
   const int nb = (NF + NV - 1) / NV;
-  f4 gobuf[2][NV][DPL], xbuf[2][NV][DPL], abuf[2][NV][DPL], wbuf[2][NV][5], gxbuf[2][NV][DPL];
+  f4 gobuf[2][NV][DPL], wbuf[2][NV][5];
   uint32_t mbuf[2][NV][DPL];
-  float Gn[DPL];
-  BwdCarry cy;
+  uint2 kbuf[2][NV];
+  float Gn[DPL], wn[5], sgn = 0.f;
 #pragma unroll
   for (int i = 0; i < DPL; i++) Gn[i] = 0.f;
 #pragma unroll
-  for (int t = 0; t < 5; t++) cy.wn[t] = 0.f;
-  cy.SGn = 0.f;
-  cy.kp = -1;
+  for (int t = 0; t < 5; t++) wn[t] = 0.f;
 
 #define GA_LOAD_BATCH(B, BUF)                                                   \
   _Pragma("unroll") for (int j = 0; j < NV; j++) {                              \
@@ -444,48 +391,34 @@ sga_bwd_rowvec(const float *__restrict__ x, const float *__restrict__ g,
     _Pragma("unroll") for (int i = 0; i < DPL; i++) {                           \
       gobuf[BUF][j][i] = *reinterpret_cast<const f4 *>(gob + eoff[i] + fo);     \
       mbuf[BUF][j][i] = *reinterpret_cast<const uint32_t *>(mb + eoff[i] + fo); \
-      xbuf[BUF][j][i] = *reinterpret_cast<const f4 *>(xb + eoff[i] + fo);       \
-      abuf[BUF][j][i] = *reinterpret_cast<const f4 *>(Ab + eoff[i] + fo);       \
-      if (accumulate) gxbuf[BUF][j][i] = *reinterpret_cast<const f4 *>(gxb + eoff[i] + fo); \
-      else { gxbuf[BUF][j][i].x = 0.f; gxbuf[BUF][j][i].y = 0.f; gxbuf[BUF][j][i].z = 0.f; gxbuf[BUF][j][i].w = 0.f; } \
     }                                                                           \
     _Pragma("unroll") for (int t = 0; t < 5; t++)                               \
       wbuf[BUF][j][t] = *reinterpret_cast<const f4 *>(gb + t * geo.HW + fo);    \
+    kbuf[BUF][j] = *reinterpret_cast<const uint2 *>(kb + fo);                   \
   }
 #define GA_COMPUTE_BATCH(B, BUF)                                                \
   _Pragma("unroll") for (int j = 0; j < NV; j++) {                              \
     const int f = (B) * NV + j;                                                 \
     if (f < NF) {                                                               \
-      f4 gxv[DPL], gwv[5];                                                      \
+      f4 ov[DPL];                                                               \
       _Pragma("unroll") for (int k = 0; k < 4; k++) {                           \
         const int kk = desc ? 3 - k : k;                                        \
-        const int kn = desc ? 3 : 0;        /* first component in visit order */ \
-        float go[DPL], xs[DPL], Am[DPL], w[5], gxo[DPL], gwo[5];                \
+        float go[DPL], w[5];                                                    \
         uint8_t mk[DPL];                                                        \
         _Pragma("unroll") for (int i = 0; i < DPL; i++) {                       \
           go[i] = f4_get(gobuf[BUF][j][i], kk);                                 \
-          xs[i] = f4_get(xbuf[BUF][j][i], kk);                                  \
           mk[i] = (uint8_t)(mbuf[BUF][j][i] >> (8 * kk));                       \
-          if (k < 3) Am[i] = f4_get(abuf[BUF][j][i], desc ? kk - 1 : kk + 1);   \
-          else if (j + 1 < NV) Am[i] = f4_get(abuf[BUF][j + 1 < NV ? j + 1 : j][i], kn); \
-          else Am[i] = f4_get(abuf[1 - BUF][0][i], kn);                         \
         }                                                                       \
         _Pragma("unroll") for (int t = 0; t < 5; t++) w[t] = f4_get(wbuf[BUF][j][t], kk); \
-        const bool has_nx = !(f == 0 && k == 0);                                \
-        const bool has_pv = !(f == NF - 1 && k == 3);                           \
-        bwd_step<GD, DPL>(go, mk, xs, Am, w, Gn, cy, gxo, gwo, has_nx, has_pv, c, geo.D, dir); \
-        _Pragma("unroll") for (int i = 0; i < DPL; i++)                         \
-          f4_set(gxv[i], kk, f4_get(gxbuf[BUF][j][i], kk) + gxo[i]);            \
-        _Pragma("unroll") for (int t = 0; t < 5; t++) f4_set(gwv[t], kk, gwo[t]); \
+        const uint32_t kw = kk < 2 ? kbuf[BUF][j].x : kbuf[BUF][j].y;           \
+        const int kpv = (int)((kw >> (16 * (kk & 1))) & 0xffffu);               \
+        bwdg_step<GD, DPL, uint8_t>(go, mk, Gn, wn, sgn, w, kpv, !(f == 0 && k == 0), c, geo.D, dir); \
+        _Pragma("unroll") for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]); \
       }                                                                         \
       const int fo = (desc ? NF - 1 - f : f) << 2;                              \
       _Pragma("unroll") for (int i = 0; i < DPL; i++)                           \
         if (c.line_ok && c.d0 + i < geo.D)                                      \
-          *reinterpret_cast<f4 *>(gxb + eoff[i] + fo) = gxv[i];                 \
-      if (c.line_ok && c.lg == 0) {                                             \
-        _Pragma("unroll") for (int t = 0; t < 5; t++)                           \
-          *reinterpret_cast<f4 *>(gwb + t * geo.HW + fo) = gwv[t];              \
-      }                                                                         \
+          *reinterpret_cast<f4 *>(Gb + eoff[i] + fo) = ov[i];                   \
     }                                                                           \
   }
 
@@ -501,23 +434,146 @@ sga_bwd_rowvec(const float *__restrict__ x, const float *__restrict__ g,
 #undef GA_COMPUTE_BATCH
 }
 
-// ---- direction merge (Max, GANet_kernel.cu:23-36, fused over the 4 volumes) --------
+// ---- per-pixel gradients for NDIR directions at once ---------------------------------------
+// One lane per pixel (n,c,h,w), marching over d.  For every direction q with adjoint volume
+// G_q and forward volume A_q, pp = the position visited just before the pixel in q's forward
+// scan (pixel offset prev_off[q]; has_prev false on the scan's first row / column):
+//   gradX[d] (+)= sum_q G_q[d]*w0_q (+ G_q[0]*w2_q at d = 0, + G_q[D-1]*w3_q at d = D-1)
+//   gw0_q = sum_d G_q[d]*x[d]
+//   gw1_q = sum_d G_q[d]*A_q[pp][d]
+//   gw2_q = G_q[0]*x[0]     + sum_{d>=1}  G_q[d]*A_q[pp][d-1]
+//   gw3_q = G_q[D-1]*x[D-1] + sum_{d<D-1} G_q[d]*A_q[pp][d+1]
+//   gw4_q = (sum_d G_q[d]) * max_d A_q[pp][d]          (gw1..4 = 0 without pp)
+struct PointArgs {
+  const float *G[4];
+  const float *A[4];
+  const float *g[4];
+  float *gw[4];
+  int dir[4];
+};
+
+template <int NDIR>
+__global__ void __launch_bounds__(256)
+sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa,
+              int D, int H, int W, i64 npix, int accumulate)
+{
+  const i64 HW = (i64)H * W;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 pidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
+    const i64 s = pidx / HW, pix = pidx - s * HW;
+    const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
+    const i64 vb = s * D * HW + pix;
+    const i64 gbo = s * 5 * HW + pix;
+    float w0[NDIR], w2[NDIR], w3[NDIR];
+    bool hp[NDIR];
+    i64 poff[NDIR];
+    float s0[NDIR], s1[NDIR], s2[NDIR], s3[NDIR], sg[NDIR], mx[NDIR];
+    float a_m[NDIR], a_0[NDIR];        // A[pp][d-1], A[pp][d]
+#pragma unroll
+    for (int q = 0; q < NDIR; q++) {
+      const int dir = pa.dir[q];
+      w0[q] = pa.g[q][gbo];
+      w2[q] = pa.g[q][gbo + 2 * HW];
+      w3[q] = pa.g[q][gbo + 3 * HW];
+      // previous position in forward order: down h-1, up h+1, right w-1, left w+1
+      hp[q] = dir == 0 ? h > 0 : dir == 1 ? h + 1 < H : dir == 2 ? w > 0 : w + 1 < W;
+      poff[q] = hp[q] ? (dir == 0 ? -(i64)W : dir == 1 ? (i64)W : dir == 2 ? -1 : 1) : 0;
+      s0[q] = s1[q] = s2[q] = s3[q] = sg[q] = 0.f;
+      mx[q] = -INFINITY;
+      a_m[q] = 0.f;
+      a_0[q] = pa.A[q][vb + poff[q]];
+    }
+    for (int d = 0; d < D; d++) {
+      const i64 o = vb + (i64)d * HW;
+      const float xv = x[o];
+      float gxv = accumulate ? gradX[o] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NDIR; q++) {
+        const float Gv = pa.G[q][o];
+        const float a_p = d + 1 < D ? pa.A[q][o + HW + poff[q]] : 0.f;   // A[pp][d+1]
+        float r = Gv * w0[q];
+        if (d == 0) r = fmaf(Gv, w2[q], r);
+        if (d == D - 1) r = fmaf(Gv, w3[q], r);
+        gxv += r;
+        s0[q] = fmaf(Gv, xv, s0[q]);
+        sg[q] += Gv;
+        s1[q] = fmaf(Gv, a_0[q], s1[q]);
+        s2[q] = fmaf(Gv, d >= 1 ? a_m[q] : xv, s2[q]);
+        s3[q] = fmaf(Gv, d + 1 < D ? a_p : xv, s3[q]);
+        mx[q] = fmaxf(mx[q], a_0[q]);
+        a_m[q] = a_0[q];
+        a_0[q] = a_p;
+      }
+      gradX[o] = gxv;
+    }
+#pragma unroll
+    for (int q = 0; q < NDIR; q++) {
+      float *gw = pa.gw[q] + gbo;
+      gw[0] = s0[q];
+      gw[HW] = hp[q] ? s1[q] : 0.f;
+      gw[2 * HW] = hp[q] ? s2[q] : 0.f;
+      gw[3 * HW] = hp[q] ? s3[q] : 0.f;
+      gw[4 * HW] = hp[q] ? sg[q] * mx[q] : 0.f;
+    }
+  }
+}
+
+// ---- direction merge + arg-max, one lane per pixel --------------------------------------------
 // out = A0; mask = 0; for dir 1..3: if (out < A_dir) { out = A_dir; mask = dir; }
+// (Max, GANet_kernel.cu:23-36, fused over the 4 volumes) and, in the same sweep,
+// kp[dir][pixel] = first-argmax_d A_dir[.][pixel] (MaxDepth, :50-64) for the backward scans.
 template <typename MaskT>
 __global__ void __launch_bounds__(256)
-sga_merge4(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
-           const float *__restrict__ A3, float *__restrict__ out, MaskT *__restrict__ mask, i64 n)
+sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
+             const float *__restrict__ A3, float *__restrict__ out, MaskT *__restrict__ mask,
+             uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
 {
   const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float o = A0[i];
-    int mk = 0;
-    const float a1 = A1[i], a2 = A2[i], a3 = A3[i];
-    if (o < a1) { o = a1; mk = 1; }
-    if (o < a2) { o = a2; mk = 2; }
-    if (o < a3) { o = a3; mk = 3; }
-    out[i] = o;
-    mask[i] = (MaskT)mk;
+  for (i64 pidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
+    const i64 s = pidx / HW, pix = pidx - s * HW;
+    const i64 vb = s * D * HW + pix;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    for (int d = 0; d < D; d++) {
+      const i64 o = vb + (i64)d * HW;
+      const float a0 = A0[o], a1 = A1[o], a2 = A2[o], a3 = A3[o];
+      float ov = a0;
+      int mk = 0;
+      if (ov < a1) { ov = a1; mk = 1; }
+      if (ov < a2) { ov = a2; mk = 2; }
+      if (ov < a3) { ov = a3; mk = 3; }
+      out[o] = ov;
+      mask[o] = (MaskT)mk;
+      if (d == 0) { m0 = a0; m1 = a1; m2 = a2; m3 = a3; }
+      else {
+        if (m0 < a0) { m0 = a0; k0 = d; }
+        if (m1 < a1) { m1 = a1; k1 = d; }
+        if (m2 < a2) { m2 = a2; k2 = d; }
+        if (m3 < a3) { m3 = a3; k3 = d; }
+      }
+    }
+    kp[pidx] = (uint16_t)k0;
+    kp[npix + pidx] = (uint16_t)k1;
+    kp[2 * npix + pidx] = (uint16_t)k2;
+    kp[3 * npix + pidx] = (uint16_t)k3;
+  }
+}
+
+// first-argmax over d of one directional volume (reference-compatible path; MaxDepth :50-64)
+__global__ void __launch_bounds__(256)
+sga_argmax_px(const float *__restrict__ A, uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
+{
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 pidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
+    const i64 s = pidx / HW, pix = pidx - s * HW;
+    const i64 vb = s * D * HW + pix;
+    float m = A[vb];
+    int k = 0;
+    for (int d = 1; d < D; d++) {
+      const float a = A[vb + (i64)d * HW];
+      if (m < a) { m = a; k = d; }
+    }
+    kp[pidx] = (uint16_t)k;
   }
 }
 

@@ -52,9 +52,10 @@ def _p(t):
 class SgaFunction(Function):
     """SgaFunction.apply(input, g0, g1, g2, g3) -> output   (functions/GANet.py:8-48).
 
-    Saves the four directional volumes and a uint8 direction mask so that backward is one
-    sweep per direction (set GANET_SGA_SAVE=recompute for the reference's memory profile:
-    save A_left + float mask, recompute the other three volumes in backward)."""
+    Saves the four directional volumes, a uint8 direction mask and the per-pixel arg-max
+    indices, so that backward is four light adjoint scans + one per-pixel gradient kernel
+    (set GANET_SGA_SAVE=recompute for the reference's memory profile: save A_left + float
+    mask, recompute the other three volumes in backward)."""
 
     @staticmethod
     def forward(ctx, input, g0, g1, g2, g3):
@@ -71,18 +72,19 @@ class SgaFunction(Function):
                 mask = torch.empty_like(input)
                 _lib().call("ganet_sga_forward_compat", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(temp_out),
                             _p(output), _p(mask), N, C, D, H, W, _stream())
-                ctx.save_for_backward(input, g0, g1, g2, g3, temp_out, mask)
+                ctx.save_for_backward(input, g0, g1, g2, g3, temp_out, mask, mask.new_empty(0))
             else:
                 A = torch.empty((4,) + tuple(input.shape), dtype=input.dtype, device=input.device)
                 mask = torch.empty(input.shape, dtype=torch.uint8, device=input.device)
+                kp = torch.empty((4, N, C, H, W), dtype=torch.int16, device=input.device)   # uint16 payload
                 _lib().call("ganet_sga_forward", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(A), _p(output),
-                            _p(mask), N, C, D, H, W, _stream())
-                ctx.save_for_backward(input, g0, g1, g2, g3, A, mask)
+                            _p(mask), _p(kp), N, C, D, H, W, _stream())
+                ctx.save_for_backward(input, g0, g1, g2, g3, A, mask, kp)
         return output
 
     @staticmethod
     def backward(ctx, gradOutput):
-        input, g0, g1, g2, g3, saved, mask = ctx.saved_tensors
+        input, g0, g1, g2, g3, saved, mask, kp = ctx.saved_tensors
         gradOutput = gradOutput.contiguous()
         _check(gradOutput)
         N, C, D, H, W = input.shape
@@ -99,8 +101,10 @@ class SgaFunction(Function):
             else:
                 gradInput = torch.empty_like(input)
                 grads = [torch.empty_like(g) for g in (g0, g1, g2, g3)]
+                G_ws = torch.empty_like(saved)        # the four adjoint volumes (scratch)
                 _lib().call("ganet_sga_backward", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(saved), _p(mask),
-                            _p(gradOutput), _p(gradInput), *[_p(g) for g in grads], N, C, D, H, W, _stream())
+                            _p(kp), _p(gradOutput), _p(G_ws), _p(gradInput), *[_p(g) for g in grads],
+                            N, C, D, H, W, _stream())
         return (gradInput, *grads)
 
 

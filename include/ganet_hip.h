@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 1
+#define GANET_ABI_VERSION 2
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -51,31 +51,41 @@ int ganet_sga_scan_forward(const float *x, const float *g, float *A,
 
 /* Fast-path forward used by ganet_amd's SgaFunction: the four directional volumes
  * are written to A_ws ([4][N*C*D*H*W] floats, caller-allocated; kept for backward),
- * out = element-wise max in reference order, mask = winning direction (uint8).
+ * out = element-wise max in reference order, mask = winning direction (uint8), and
+ * kp ([4][N*C*H*W] uint16) = first-argmax over d of every directional volume.
  * Replaces: sga_kernel_forward (GANet_kernel.cu:935-998) incl. the three `Max`
- * launches (:23-36) and five device memcpys. */
+ * launches (:23-36) and five device memcpys; kp is what MaxDepth (:50-64) recomputes
+ * four times in the reference's backward. */
 int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
-                      const float *g3, float *A_ws, float *out, uint8_t *mask,
+                      const float *g3, float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
                       int N, int C, int D, int H, int W, void *stream);
 
-/* One direction of the backward pass, single sweep: masked gather of gradOutput,
- * first-argmax routing, reverse-scan adjoint, all five guidance-weight reductions.
- * gradX: written (accumulate = 0) or accumulated into (accumulate = 1); gw
- * ([N,C,5,H,W]) is written.
- * Replaces: cudaMemset + get_temp_grad (:38-48) + MaxDepth (:50-64) +
- *           sga_*_data_backward (:129-208 & mirrors) + sga_*_weight_backward
- *           (:210-281 & mirrors). */
+/* Reverse-scan adjoint of one direction: G = [mask == dir] * grad_out propagated through the
+ * recurrence with first-argmax routing (kp_dir: [N*C*H*W] uint16 of that direction).
+ * Replaces: cudaMemset + get_temp_grad (:38-48) + the top_diff part of
+ *           sga_*_data_backward (:144-181 & mirrors). */
+int ganet_sga_backward_scan(const float *g, const uint8_t *mask, const uint16_t *kp_dir,
+                            const float *grad_out, float *G,
+                            int N, int C, int D, int H, int W, int dir, void *stream);
+
+/* One direction of the backward pass: adjoint scan into G_ws ([N*C*D*H*W] scratch) followed by
+ * the per-pixel gradient kernel.  grad_x: written (accumulate = 0) or accumulated into
+ * (accumulate = 1); gw ([N,C,5,H,W]) is written.
+ * Replaces: cudaMemset + get_temp_grad + MaxDepth + sga_*_data_backward (:129-208 & mirrors)
+ *           + sga_*_weight_backward (:210-281 & mirrors). */
 int ganet_sga_backward_dir(const float *x, const float *g, const float *A, const uint8_t *mask,
-                           const float *grad_out, float *grad_x, float *gw,
+                           const uint16_t *kp_dir, const float *grad_out, float *G_ws,
+                           float *grad_x, float *gw,
                            int N, int C, int D, int H, int W, int dir, int accumulate,
                            void *stream);
 
-/* Fast-path backward: all four directions from the volumes saved by
- * ganet_sga_forward.  grad_x and gw0..gw3 are fully overwritten.
+/* Fast-path backward: four adjoint scans into G_ws ([4][N*C*D*H*W] scratch) + ONE per-pixel
+ * kernel for all gradients, from the volumes / mask / kp saved by ganet_sga_forward.
+ * grad_x and gw0..gw3 are fully overwritten.
  * Replaces: sga_kernel_backward (GANet_kernel.cu:1000-1129). */
 int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
-                       const float *g3, const float *A_ws, const uint8_t *mask,
-                       const float *grad_out, float *grad_x, float *gw0, float *gw1,
+                       const float *g3, const float *A_ws, const uint8_t *mask, const uint16_t *kp,
+                       const float *grad_out, float *G_ws, float *grad_x, float *gw0, float *gw1,
                        float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
 
 /* Reference-compatible buffer contract, for callers that keep the reference's
@@ -84,9 +94,10 @@ int ganet_sga_backward(const float *x, const float *g0, const float *g1, const f
  *   sga_cuda_backward(input, g0..g3, temp_out, mask, max_idx, gradOutput, temp_grad,
  *                     gradInput, grad0..grad3)                    GANet_cuda.cpp:50-64
  * mask is float-valued; temp_out ends the forward holding A_left and is reused as
- * scratch by the backward (which recomputes the other three volumes); temp_grad is
- * scratch; gradInput / grad0..3 are ACCUMULATED into (the caller zero-fills them,
- * functions/GANet.py:33-37); max_idx is left untouched (scratch in the reference). */
+ * scratch by the backward (which recomputes the other three volumes); temp_grad and
+ * max_idx are scratch (adjoint volume / per-pixel arg-max, as in the reference);
+ * gradInput is ACCUMULATED into (the caller zero-fills it, functions/GANet.py:33);
+ * grad0..3 are written. */
 int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1, const float *g2,
                              const float *g3, float *temp_out, float *out, float *mask_f32,
                              int N, int C, int D, int H, int W, void *stream);

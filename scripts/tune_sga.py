@@ -26,8 +26,8 @@ for gd, bv, rw in itertools.product([4, 8], [64, 128, 256], [0, 1]):
     row = {"gd_v": gd, "block_v": bv, "rowwave": rw,
            "fwd_v": round(st["sga_scan_fwd_down"] + st["sga_scan_fwd_up"], 3),
            "fwd_h": round(st["sga_scan_fwd_right"] + st["sga_scan_fwd_left"], 3),
-           "bwd_v": round(st["sga_bwd_down"] + st["sga_bwd_up"], 3),
-           "bwd_h": round(st["sga_bwd_right"] + st["sga_bwd_left"], 3),
-           "fused_fwd": round(st["sga_forward_fused_call"], 3)}
+           "bwdg_v": round(st["sga_bwd_scan_down"] + st["sga_bwd_scan_up"], 3),
+           "bwdg_h": round(st["sga_bwd_scan_right"] + st["sga_bwd_scan_left"], 3),
+           "fwd_call": round(st["sga_forward_call"], 3), "bwd_call": round(st["sga_backward_call"], 3)}
     rows.append(row)
     print(json.dumps(row), flush=True)

@@ -36,6 +36,8 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct alignas(8) uint2 { unsigned x, y; };
+
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
 typedef int hipError_t;

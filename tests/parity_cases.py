@@ -27,7 +27,9 @@ class NumpyDev:
         return np.ascontiguousarray(a)
 
     def empty(self, shape, dtype=np.float32):
-        return np.empty(shape, dtype)
+        a = np.empty(shape, dtype)
+        a.fill(np.nan if dtype == np.float32 else 113)     # poison: unwritten elements get noticed
+        return a
 
     def zeros(self, shape, dtype=np.float32):
         return np.zeros(shape, dtype)
@@ -60,28 +62,43 @@ def run_sga_forward(api, dev, x, gs):
     A = dev.empty((4,) + x.shape)
     out = dev.empty(x.shape)
     mask = dev.empty(x.shape, np.uint8)
+    kp = dev.empty((4, N, C, H, W), np.uint16)
     api.call("ganet_sga_forward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(out), dev.ptr(mask),
-             N, C, D, H, W, dev.stream)
+             dev.ptr(kp), N, C, D, H, W, dev.stream)
     dev.sync()
-    return dx, dg, A, out, mask
+    return dx, dg, A, out, mask, kp
 
 
 def check_sga_forward_backward(api, dev, x, gs, go, want):
     """want: dict(out, mask(uint8), gx, gw0..gw3, optional A0..A3) from the oracle/golden."""
     N, C, D, H, W = x.shape
-    dx, dg, A, out, mask = run_sga_forward(api, dev, x, gs)
+    dx, dg, A, out, mask, kp = run_sga_forward(api, dev, x, gs)
     hA = dev.host(A)
     for d in range(4):
         if f"A{d}" in want:
             assert np.array_equal(hA[d], want[f"A{d}"]), f"A{d}"
     assert np.array_equal(dev.host(out), want["out"]), "out"
     assert np.array_equal(dev.host(mask), want["mask"]), "direction mask must be bit-exact"
+    # arg-max indices: first maximum over d of each directional volume (MaxDepth semantics)
+    assert np.array_equal(dev.host(kp).astype(np.int64), np.argmax(hA, axis=3)), "arg-max must be bit-exact"
     dgo = dev.to(go)
     gx = dev.empty(x.shape)
     gw = [dev.empty(gs[0].shape) for _ in range(4)]
-    api.call("ganet_sga_backward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(mask), dev.ptr(dgo),
-             dev.ptr(gx), *[dev.ptr(g) for g in gw], N, C, D, H, W, dev.stream)
+    G = dev.empty((4,) + x.shape)
+    api.call("ganet_sga_backward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(mask), dev.ptr(kp),
+             dev.ptr(dgo), dev.ptr(G), dev.ptr(gx), *[dev.ptr(g) for g in gw], N, C, D, H, W, dev.stream)
     dev.sync()
+    # the per-direction entry point must agree with the fused one
+    gx1 = dev.empty(x.shape)
+    G1 = dev.empty(x.shape)
+    for d in range(4):
+        gw1 = dev.empty(gs[0].shape)
+        api.call("ganet_sga_backward_dir", dev.ptr(dx), dev.ptr(dg[d]), dev.ptr(A) + 4 * d * x.size,
+                 dev.ptr(mask), dev.ptr(kp) + 2 * d * (N * C * H * W), dev.ptr(dgo), dev.ptr(G1), dev.ptr(gx1),
+                 dev.ptr(gw1), N, C, D, H, W, d, 1 if d else 0, dev.stream)
+        dev.sync()
+        assert np.abs(dev.host(gw1) - dev.host(gw[d])).max() <= 1e-6
+    assert np.abs(dev.host(gx1) - dev.host(gx)).max() <= 1e-5
     err = {"gx": float(np.abs(dev.host(gx) - want["gx"]).max())}
     for d in range(4):
         err[f"gw{d}"] = float(np.abs(dev.host(gw[d]) - want[f"gw{d}"]).max())

@@ -23,7 +23,8 @@ class TorchDev:
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
     def _dt(self, dtype):
-        return {np.float32: self.torch.float32, np.uint8: self.torch.uint8, np.int32: self.torch.int32}[dtype]
+        return {np.float32: self.torch.float32, np.uint8: self.torch.uint8, np.int32: self.torch.int32,
+                np.uint16: self.torch.int16}[dtype]
 
     def empty(self, shape, dtype=np.float32):
         # poison so that an element the kernel fails to write is noticed
@@ -37,7 +38,8 @@ class TorchDev:
         return t.data_ptr()
 
     def host(self, t):
-        return t.cpu().numpy()
+        a = t.cpu().numpy()
+        return a.view(np.uint16) if a.dtype == np.int16 else a
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -79,7 +81,7 @@ def test_sga_golden(api, dev, name):
 def test_sga_cfg1_golden_forward(api, dev):
     """BASELINE.json configs[0]: 1x48x48x48 (C=1) forward."""
     z = load("sga_cfg1_golden.npz")
-    _, _, _, out, mask = pc.run_sga_forward(api, dev, z["x"], [z[f"g{d}"] for d in range(4)])
+    _, _, _, out, mask, _ = pc.run_sga_forward(api, dev, z["x"], [z[f"g{d}"] for d in range(4)])
     assert np.array_equal(dev.host(out), z["out"])
     assert np.array_equal(dev.host(mask), z["mask"])
 
@@ -128,8 +130,8 @@ def test_sga_single_stream_equals_multi_stream(api, dev):
     res = []
     for streams in (0, 1):
         api.set_option("GANET_SGA_STREAMS", streams)
-        _, _, A, out, mask = pc.run_sga_forward(api, dev, x, gs)
-        res.append((dev.host(A), dev.host(out), dev.host(mask)))
+        _, _, A, out, mask, kp = pc.run_sga_forward(api, dev, x, gs)
+        res.append((dev.host(A), dev.host(out), dev.host(mask), dev.host(kp)))
     api.set_option("GANET_SGA_STREAMS", 0)
     for a, b in zip(*res):
         assert np.array_equal(a, b)
@@ -179,8 +181,8 @@ def test_full_size_properties(api, dev):
     the direction mask unchanged; LGA is bilinear, so <y, gy> == <x, gX> == <f, gF>."""
     torch = dev.torch
     x, gs, _ = pc.sga_inputs((1, 32, 65, 80, 208), seed=5)
-    _, _, _, out1, mask1 = pc.run_sga_forward(api, dev, x, gs)
-    _, _, _, out2, mask2 = pc.run_sga_forward(api, dev, 2.0 * x, gs)
+    _, _, _, out1, mask1, _ = pc.run_sga_forward(api, dev, x, gs)
+    _, _, _, out2, mask2, _ = pc.run_sga_forward(api, dev, 2.0 * x, gs)
     assert torch.equal(out2, 2.0 * out1) and torch.equal(mask1, mask2)
     g = torch.Generator(device="cuda").manual_seed(9)
     B, D, H, W = 1, 193, 240, 624
