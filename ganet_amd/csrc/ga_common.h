@@ -36,6 +36,17 @@ extern __shared__ __attribute__((aligned(16))) float ga_dyn_smem_raw[];
 #define GA_DYN_SMEM(name) float *name = ga::ga_dyn_smem_raw
 #endif
 
+// packed fp32 pair: v_pk_fma_f32 does two FMAs per lane per issue on gfx950 (the 157 TF fp32
+// vector peak assumes it); hipcc emits it for ext_vector_type(2) elementwise fma.
+#if defined(GA_HIPSIM)
+struct f2 { float x, y; };
+GA_DEV f2 fma2(f2 a, f2 b, f2 c) { f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
+#else
+typedef float f2 __attribute__((ext_vector_type(2)));
+GA_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+
 GA_DEV float f4_get(const f4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 GA_DEV void f4_set(f4 &v, int k, float a)
 {

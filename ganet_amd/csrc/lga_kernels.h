@@ -36,15 +36,32 @@ namespace ga {
 constexpr int LGA_TW = 32;   // tile width  (pixels, = lanes along W)
 constexpr int LGA_TH = 8;    // tile height
 constexpr int LGA_PB = 4;    // planes per LDS stage
+#ifndef LGA_WAVES_PER_SIMD
+#define LGA_WAVES_PER_SIMD 3   // register cap: the march is latency-bound, occupancy pays
+#endif
 
+// Aligned-window layout.  The tile's column halo is rounded up to an even width RE, so tile
+// column 0 sits at an even LDS offset; a lane whose (2R+1)-wide window starts at an odd tile
+// column (par = 1) reads from one column earlier.  Every lane therefore fetches the SAME shape
+// -- NP = R+1 eight-byte-aligned ds_read_b64 per tile row (256 B/clk, twice the ds_read2_b32
+// rate; neighbouring lanes of a pair read identical addresses, which broadcast) -- and the
+// parity is folded into the WEIGHTS once per kernel: w6[k] = w[k - par], zero outside.  Each
+// b64 result is a natural even-aligned register pair, which is exactly what v_pk_fma_f32 wants:
+//   (slab -1, slab 0) accumulators += (v_k, v_k) * (w6a[k], w6b[k])       2 per pair
+//   slab +1 accumulator pair       += (v_2q, v_2q+1) * (w6c[2q], w6c[2q+1])  1 per pair
+// = 3*NP packed FMAs per row (45 per plane at R = 2, against 75 scalar FMAs + 25 LDS dwords in
+// the first version, profiles/r1b_pmc_summary.txt).
 template <int R> struct LgaCfg {
   static constexpr int WS = 2 * R + 1;
   static constexpr int K = WS * WS;
-  static constexpr int TW2 = LGA_TW + 2 * R;
+  static constexpr int RE = (R + 1) & ~1;            // even column halo
+  static constexpr int NP = R + 1;                   // b64 pairs per window
+  static constexpr int NK = 2 * NP;                  // window slots (one is a zero-weight dummy)
+  static constexpr int TW2 = LGA_TW + 2 * RE;        // even
   static constexpr int TH2 = LGA_TH + 2 * R;
   static constexpr int PLANE = TW2 * TH2;
   static constexpr int STAGE = PLANE * LGA_PB;
-  static constexpr int NLD = (STAGE + 255) / 256;   // staged elements per thread
+  static constexpr int NLD = (STAGE + 255) / 256;    // staged elements per thread
 };
 
 struct LgaGeom {
@@ -52,25 +69,40 @@ struct LgaGeom {
   i64 HW;
 };
 
-// cooperative stage load: planes [d0, d0+PB) of the tile (+halo) -> registers
+// Cooperative stage load: planes [d0, d0+PB) of the tile (+halo) -> registers -> LDS.
+// Which tile cell a thread copies does not depend on the chunk, so the (plane-in-chunk,
+// element offset, in-image) triple is computed ONCE per kernel.
+template <int R> struct LgaStage {
+  int off[LgaCfg<R>::NLD];     // element offset from the chunk's first plane, or -1 = write zero
+  int pl[LgaCfg<R>::NLD];      // plane within the chunk
+};
 template <int R>
-GA_DEV void lga_stage_fetch(const float *__restrict__ xb, const LgaGeom &geo, int ty0, int tx0,
-                            int d0, float (&regs)[LgaCfg<R>::NLD])
+GA_DEV void lga_stage_init(LgaStage<R> &st, const LgaGeom &geo, int ty0, int tx0)
 {
   typedef LgaCfg<R> C;
 #pragma unroll
   for (int l = 0; l < C::NLD; l++) {
     const int e = l * 256 + (int)threadIdx.x;
-    float v = 0.f;
+    st.off[l] = -1;
+    st.pl[l] = 0;
     if (e < C::STAGE) {
       const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
       const int r = rem / C::TW2, cc = rem - r * C::TW2;
-      const int d = d0 + pl, i = ty0 + r - R, j = tx0 + cc - R;
-      if (d < geo.D && i >= 0 && i < geo.H && j >= 0 && j < geo.W)
-        v = xb[(i64)d * geo.HW + (i64)i * geo.W + j];
+      const int i = ty0 + r - R, j = tx0 + cc - C::RE;
+      st.pl[l] = pl;
+      if (i >= 0 && i < geo.H && j >= 0 && j < geo.W) st.off[l] = (int)(pl * geo.HW + (i64)i * geo.W + j);
     }
-    regs[l] = v;
   }
+}
+template <int R>
+GA_DEV void lga_stage_fetch(const float *__restrict__ xb, const LgaGeom &geo, const LgaStage<R> &st,
+                            int d0, float (&regs)[LgaCfg<R>::NLD])
+{
+  typedef LgaCfg<R> C;
+  const float *base = xb + (i64)d0 * geo.HW;
+#pragma unroll
+  for (int l = 0; l < C::NLD; l++)
+    regs[l] = (st.off[l] >= 0 && d0 + st.pl[l] < geo.D) ? base[st.off[l]] : 0.f;
 }
 template <int R>
 GA_DEV void lga_stage_commit(float *__restrict__ buf, const float (&regs)[LgaCfg<R>::NLD])
@@ -86,12 +118,12 @@ GA_DEV void lga_stage_commit(float *__restrict__ buf, const float (&regs)[LgaCfg
 // ---- forward (TRANSPOSED = false) and data-backward (TRANSPOSED = true) ---------
 // y[b,d,i,j] = sum_t w_t * xs(d+dd, i+a, j+b)  with centre replacement.
 template <int R, bool TRANSPOSED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, LGA_WAVES_PER_SIMD)
 lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
           LgaGeom geo)
 {
   typedef LgaCfg<R> C;
-  __shared__ float tile[2][C::STAGE];
+  __shared__ __attribute__((aligned(16))) float tile[2][C::STAGE];
   const int tx = threadIdx.x % LGA_TW, ty = threadIdx.x / LGA_TW;
   const int tx0 = blockIdx.x * LGA_TW, ty0 = blockIdx.y * LGA_TH;
   const int b = blockIdx.z;
@@ -102,69 +134,107 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
   const float *fb = f + (i64)b * 3 * C::K * geo.HW;
   float *yb = y + (i64)b * geo.D * geo.HW;
   const i64 pix = (i64)ic * geo.W + jc;
+  const int wcol = tx + C::RE - R;          // tile column where the window starts
+  const int par = wcol & 1;                 // 1: the aligned read starts one column earlier
+  const int rcol = wcol - par;              // even
 
-  // per-pixel weights and centre coefficients
-  float w[3][C::K];
+  // per-pixel weights (parity-shifted, packed) and centre coefficients
+  f2 wab[C::WS][C::NK];                     // (slab -1, slab 0) of window slot k
+  f2 wc[C::WS][C::NP];                      // slab +1 of slots (2q, 2q+1)
   float cmid = 0.f, sin_m = 0.f, sin_p = 0.f;
-#pragma unroll
-  for (int dd = 0; dd < 3; dd++) {
+  {
 #pragma unroll
     for (int a = -R; a <= R; a++) {
+      float wt[3][C::WS];
 #pragma unroll
-      for (int bb = -R; bb <= R; bb++) {
-        const int t = dd * C::K + (a + R) * C::WS + (bb + R);
-        const int i2 = ic + a, j2 = jc + bb;
-        const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
-        const float own = fb[(i64)t * geo.HW + pix];
-        float wv = own;
-        if (TRANSPOSED) {
-          const int tf = (2 - dd) * C::K + (-a + R) * C::WS + (-bb + R);
-          wv = ok ? fb[(i64)tf * geo.HW + (i64)i2 * geo.W + j2] : 0.f;
+      for (int dd = 0; dd < 3; dd++) {
+#pragma unroll
+        for (int bb = -R; bb <= R; bb++) {
+          const int t = dd * C::K + (a + R) * C::WS + (bb + R);
+          const int i2 = ic + a, j2 = jc + bb;
+          const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
+          const float own = fb[(i64)t * geo.HW + pix];
+          float wv = own;
+          if (TRANSPOSED) {
+            const int tf = (2 - dd) * C::K + (-a + R) * C::WS + (-bb + R);
+            wv = ok ? fb[(i64)tf * geo.HW + (i64)i2 * geo.W + j2] : 0.f;
+          }
+          wt[dd][bb + R] = ok ? wv : 0.f;
+          if (!ok) cmid += own;
+          else if (dd == 0) sin_m += own;
+          else if (dd == 2) sin_p += own;
         }
-        w[dd][(a + R) * C::WS + (bb + R)] = ok ? wv : 0.f;
-        if (!ok) cmid += own;
-        else if (dd == 0) sin_m += own;
-        else if (dd == 2) sin_p += own;
       }
+      float w6[3][C::NK];
+#pragma unroll
+      for (int dd = 0; dd < 3; dd++)
+#pragma unroll
+        for (int k = 0; k < C::NK; k++) {
+          const float we = k < C::WS ? wt[dd][k < C::WS ? k : 0] : 0.f;            // par = 0: slot k = tap k
+          const float wo = k >= 1 ? wt[dd][k >= 1 ? k - 1 : 0] : 0.f;              // par = 1: slot k = tap k-1
+          w6[dd][k] = par ? wo : we;
+        }
+#pragma unroll
+      for (int k = 0; k < C::NK; k++) wab[a + R][k] = mk2(w6[0][k], w6[1][k]);
+#pragma unroll
+      for (int q = 0; q < C::NP; q++) wc[a + R][q] = mk2(w6[2][2 * q], w6[2][2 * q + 1]);
     }
   }
 
   const int nchunks = (geo.D + LGA_PB - 1) / LGA_PB;
+  LgaStage<R> stg;
+  lga_stage_init<R>(stg, geo, ty0, tx0);
   float regs[C::NLD];
-  lga_stage_fetch<R>(xb, geo, ty0, tx0, 0, regs);
+  lga_stage_fetch<R>(xb, geo, stg, 0, regs);
   lga_stage_commit<R>(tile[0], regs);
   __syncthreads();
 
   float acc_a = 0.f, acc_b = 0.f;   // partial y[d-1], y[d] while visiting plane d
   float xc_prev = 0.f;
+  float *yp = yb + pix;               // output cursor: plane d-1 of the own pixel
   for (int c = 0; c < nchunks; c++) {
     const bool more = c + 1 < nchunks;
-    if (more) lga_stage_fetch<R>(xb, geo, ty0, tx0, (c + 1) * LGA_PB, regs);
+    if (more) lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);
     const float *buf = tile[c & 1];
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
       const int d = c * LGA_PB + pl;
       if (d < geo.D) {
-        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + tx;
-        float zm = 0.f, z0 = 0.f, zp = 0.f;
+        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
+        // four independent accumulator chains (a single chain of dependent v_pk_fma_f32 was
+        // slower than three scalar chains; 15 chains cost registers -> occupancy)
+        f2 s_x = mk2(0.f, 0.f), s_y = mk2(0.f, 0.f), s_p0 = mk2(0.f, 0.f), s_p1 = mk2(0.f, 0.f);
+        float xc = 0.f;
 #pragma unroll
         for (int a = 0; a < C::WS; a++) {
 #pragma unroll
-          for (int bb = 0; bb < C::WS; bb++) {
-            const float v = pb[a * C::TW2 + bb];
-            zm = fmaf(v, w[0][a * C::WS + bb], zm);   // dd = -1 -> y[d+1]
-            z0 = fmaf(v, w[1][a * C::WS + bb], z0);   // dd =  0 -> y[d]
-            zp = fmaf(v, w[2][a * C::WS + bb], zp);   // dd = +1 -> y[d-1]
+          for (int q = 0; q < C::NP; q++) {
+            const f2 vv = *reinterpret_cast<const f2 *>(pb + a * C::TW2 + 2 * q);
+            s_x = fma2(mk2(vv.x, vv.x), wab[a][2 * q], s_x);
+            s_y = fma2(mk2(vv.y, vv.y), wab[a][2 * q + 1], s_y);
+            if (a & 1) s_p1 = fma2(vv, wc[a][q], s_p1);
+            else s_p0 = fma2(vv, wc[a][q], s_p0);
+            if (a == R && 2 * q <= R && R <= 2 * q + 1) {
+              // centre sample: slot R (par 0) or R+1 (par 1)
+              const float c0 = (R & 1) ? vv.y : vv.x;
+              xc = par ? xc : c0;
+            }
+            if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
+              const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
+              xc = par ? c1 : xc;
+            }
           }
         }
-        const float xc = pb[R * C::TW2 + R];
+        const float zm = s_x.x + s_y.x;                       // depth slab -1 -> y[d+1]
+        const float z0 = s_x.y + s_y.y;                       // depth slab  0 -> y[d]
+        const float zp = (s_p0.x + s_p0.y) + (s_p1.x + s_p1.y);   // depth slab +1 -> y[d-1]
         if (d >= 1) {
           const int dy = d - 1;
           float cc = cmid;
           if (dy == 0) cc += sin_m;
-          if (dy == geo.D - 1) cc += sin_p;   // unreachable here (dy <= D-2), kept for clarity
           const float r = fmaf(xc_prev, cc, acc_a + zp);
-          if (inb) yb[(i64)dy * geo.HW + pix] = r;
+          if (inb) *yp = r;
+          yp += geo.HW;
         }
         acc_a = acc_b + z0;
         acc_b = zm;
@@ -179,19 +249,19 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
     float cc = cmid + sin_p;
     if (dy == 0) cc += sin_m;
     const float r = fmaf(xc_prev, cc, acc_a);
-    if (inb) yb[(i64)dy * geo.HW + pix] = r;
+    if (inb) *yp = r;
   }
 }
 
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)
 template <int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, LGA_WAVES_PER_SIMD)
 lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
                 LgaGeom geo, int accumulate)
 {
   typedef LgaCfg<R> C;
-  __shared__ float tile[2][C::STAGE];
+  __shared__ __attribute__((aligned(16))) float tile[2][C::STAGE];
   const int tx = threadIdx.x % LGA_TW, ty = threadIdx.x / LGA_TW;
   const int tx0 = blockIdx.x * LGA_TW, ty0 = blockIdx.y * LGA_TH;
   const int b = blockIdx.z;
@@ -202,45 +272,74 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
   const float *gyb = gy + (i64)b * geo.D * geo.HW;
   float *gfb = gf + (i64)b * 3 * C::K * geo.HW;
   const i64 pix = (i64)ic * geo.W + jc;
+  const int wcol = tx + C::RE - R;
+  const int par = wcol & 1;
+  const int rcol = wcol - par;
 
-  float acc[3][C::K];
+  // partial sums per window slot: sab[a][k] = (slab -1, slab 0), sc[a][q] = slab +1 of (2q, 2q+1)
+  f2 sab[C::WS][C::NK], sc[C::WS][C::NP];
 #pragma unroll
-  for (int dd = 0; dd < 3; dd++)
+  for (int a = 0; a < C::WS; a++) {
 #pragma unroll
-    for (int t = 0; t < C::K; t++) acc[dd][t] = 0.f;
+    for (int k = 0; k < C::NK; k++) sab[a][k] = mk2(0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < C::NP; q++) sc[a][q] = mk2(0.f, 0.f);
+  }
   float gc = 0.f;                 // sum_d gy[d] * x[d][centre]
   float e_lo = 0.f, e_hi = 0.f;   // gy[0]*x[0][c], gy[D-1]*x[D-1][c]
 
   const int nchunks = (geo.D + LGA_PB - 1) / LGA_PB;
+  LgaStage<R> stg;
+  lga_stage_init<R>(stg, geo, ty0, tx0);
   float regs[C::NLD];
-  lga_stage_fetch<R>(xb, geo, ty0, tx0, 0, regs);
+  lga_stage_fetch<R>(xb, geo, stg, 0, regs);
   lga_stage_commit<R>(tile[0], regs);
   __syncthreads();
 
-  // gy at planes d-1, d, d+1 of the own pixel (rolling)
-  float g_m = 0.f, g_0 = gyb[pix], g_p = 0.f;
+  // gy of the own pixel at planes d-1, d, d+1 (rolling); the next chunk's values are fetched
+  // one chunk ahead so the march never waits on a dependent global load
+  float g_m = 0.f, g_0 = gyb[pix];
+  float gnext[LGA_PB];
+#pragma unroll
+  for (int pl = 0; pl < LGA_PB; pl++) gnext[pl] = pl + 1 < geo.D ? gyb[(i64)(pl + 1) * geo.HW + pix] : 0.f;
   for (int c = 0; c < nchunks; c++) {
     const bool more = c + 1 < nchunks;
-    if (more) lga_stage_fetch<R>(xb, geo, ty0, tx0, (c + 1) * LGA_PB, regs);
+    if (more) lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);
+    float gcur[LGA_PB];
+#pragma unroll
+    for (int pl = 0; pl < LGA_PB; pl++) {
+      gcur[pl] = gnext[pl];
+      const int dn = (c + 1) * LGA_PB + pl + 1;
+      gnext[pl] = dn < geo.D ? gyb[(i64)dn * geo.HW + pix] : 0.f;
+    }
     const float *buf = tile[c & 1];
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
       const int d = c * LGA_PB + pl;
       if (d < geo.D) {
-        g_p = d + 1 < geo.D ? gyb[(i64)(d + 1) * geo.HW + pix] : 0.f;
-        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + tx;
-        // plane d pairs with gy[d+1] for dd=-1, gy[d] for dd=0, gy[d-1] for dd=+1
+        const float g_p = gcur[pl];                       // gy[d+1] (0 past the end)
+        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
+        // plane d pairs with gy[d+1] for slab -1, gy[d] for slab 0, gy[d-1] for slab +1
+        const f2 g01 = mk2(g_p, g_0), gmm = mk2(g_m, g_m);
+        float xc = 0.f;
 #pragma unroll
         for (int a = 0; a < C::WS; a++) {
 #pragma unroll
-          for (int bb = 0; bb < C::WS; bb++) {
-            const float v = pb[a * C::TW2 + bb];
-            acc[0][a * C::WS + bb] = fmaf(g_p, v, acc[0][a * C::WS + bb]);
-            acc[1][a * C::WS + bb] = fmaf(g_0, v, acc[1][a * C::WS + bb]);
-            acc[2][a * C::WS + bb] = fmaf(g_m, v, acc[2][a * C::WS + bb]);
+          for (int q = 0; q < C::NP; q++) {
+            const f2 vv = *reinterpret_cast<const f2 *>(pb + a * C::TW2 + 2 * q);
+            sab[a][2 * q] = fma2(mk2(vv.x, vv.x), g01, sab[a][2 * q]);
+            sab[a][2 * q + 1] = fma2(mk2(vv.y, vv.y), g01, sab[a][2 * q + 1]);
+            sc[a][q] = fma2(vv, gmm, sc[a][q]);
+            if (a == R && 2 * q <= R && R <= 2 * q + 1) {
+              const float c0 = (R & 1) ? vv.y : vv.x;
+              xc = par ? xc : c0;
+            }
+            if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
+              const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
+              xc = par ? c1 : xc;
+            }
           }
         }
-        const float xc = pb[R * C::TW2 + R];
         const float e = g_0 * xc;
         gc += e;
         if (d == 0) e_lo = e;
@@ -263,7 +362,16 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
           const int t = dd * C::K + (a + R) * C::WS + (bb + R);
           const int i2 = i + a, j2 = j + bb;
           const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
-          float r = acc[dd][(a + R) * C::WS + (bb + R)];
+          // tap bb lives in window slot k = (bb + R) + par
+          const int ke = bb + R, ko = bb + R + 1, ra = a + R;
+          float re, ro;
+          if (dd == 0) { re = sab[ra][ke].x; ro = sab[ra][ko].x; }
+          else if (dd == 1) { re = sab[ra][ke].y; ro = sab[ra][ko].y; }
+          else {
+            re = (ke & 1) ? sc[ra][ke >> 1].y : sc[ra][ke >> 1].x;
+            ro = (ko & 1) ? sc[ra][ko >> 1].y : sc[ra][ko >> 1].x;
+          }
+          float r = par ? ro : re;
           if (dd == 0) r += e_lo;
           if (dd == 2) r += e_hi;
           if (!ok) r = gc;

@@ -1,0 +1,11 @@
+"""LGA micro-benchmark: forward pass, filter-grad + data-grad pass at the cfg2 shape."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ganet_amd import _native
+lib = _native.lib()
+inp = bench.make_inputs(torch.device("cuda:0"))
+st = bench.stage_timings(inp, iters=10)
+print({k: round(v, 4) for k, v in st.items() if k.startswith("lga")})
