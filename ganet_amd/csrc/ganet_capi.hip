@@ -184,14 +184,15 @@ int launch_scan_fwd(const float *x, const float *g, float *A, int S, int D, int 
 {
   const Options &o = opts();
   ScanGeom geo = make_geom(S, D, H, W, dir, false);
-  const bool rowvec = dir >= 2 && (W % 4 == 0) && aligned16(x) && aligned16(g) && aligned16(A);
+  const bool rowvec = DPL <= 17 && dir >= 2 && (W % 4 == 0) && aligned16(x) && aligned16(g) && aligned16(A);
   int block = dir < 2 ? o.block_v : o.block_h;
   if (block < 64 || block > 256 || block % 64) block = 64;
   const int lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
   if (rowvec) {
-    GA_LAUNCH((sga_fwd_rowvec<GD, DPL, fwd_nv(DPL)>), dim3(grid), dim3(block), st, x, g, A, geo,
-              dir == 3 ? 1 : 0);
+    if constexpr (DPL <= 17)
+      GA_LAUNCH((sga_fwd_rowvec<GD, DPL, fwd_nv(DPL)>), dim3(grid), dim3(block), st, x, g, A, geo,
+                dir == 3 ? 1 : 0);
   } else {
     GA_LAUNCH((sga_fwd_strided<GD, DPL, fwd_sb(DPL)>), dim3(grid), dim3(block), st, x, g, A, geo);
   }
@@ -204,16 +205,17 @@ int launch_scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, co
 {
   const Options &o = opts();
   ScanGeom geo = make_geom(S, D, H, W, dir, true);
-  const bool rowvec = dir >= 2 && (W % 4 == 0) && aligned16(g) && aligned16(gout) && aligned16(G) &&
-                      (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
+  const bool rowvec = DPL <= 17 && dir >= 2 && (W % 4 == 0) && aligned16(g) && aligned16(gout) &&
+                      aligned16(G) && (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
   int block = dir < 2 ? o.block_v : o.block_h;
   if (block < 64 || block > 256 || block % 64) block = 64;
   const int lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
   if (rowvec) {
     // the adjoint of `right` (2) visits w descending, of `left` (3) ascending
-    GA_LAUNCH((sga_bwdg_rowvec<GD, DPL, bwd_nv(DPL)>), dim3(grid), dim3(block), st, g, mask, kp, gout,
-              G, geo, dir, dir == 2 ? 1 : 0);
+    if constexpr (DPL <= 17)
+      GA_LAUNCH((sga_bwdg_rowvec<GD, DPL, bwd_nv(DPL)>), dim3(grid), dim3(block), st, g, mask, kp, gout,
+                G, geo, dir, dir == 2 ? 1 : 0);
   } else {
     GA_LAUNCH((sga_bwdg_strided<GD, DPL, bwd_sb(DPL), uint8_t>), dim3(grid), dim3(block), st, g, mask,
               kp, gout, G, geo, dir);
@@ -252,6 +254,14 @@ size_t row_smem_fwd(int D)
 {
   return sizeof(float) * ROW_LN_F * ((size_t)2 * D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
 }
+constexpr int ROW_SBH_B = 16, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
+size_t row_smem_bwdg(int D)
+{
+  const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH_B, ROW_PAD_B>::PP + 1) + 3) & ~(size_t)3;
+  return sizeof(float) * ROW_LN_B * ((size_t)D * RowCfg<ROW_SBH_B, ROW_PAD_B>::RS + mask_words + 5 * ROW_SBH_B +
+                                     ROW_SBH_B / 2);
+}
+
 bool rowwave_ok(int D, int W, int dir, size_t smem)
 {
   return opts().rowwave && dir >= 2 && W % 4 == 0 && D <= 16 * 13 && smem <= ROW_SMEM_MAX;
@@ -286,6 +296,25 @@ int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
   return check_launch("sga row forward");
 }
 
+int row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
+             int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  RowGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
+  const int dpl = row_dpl(D);
+  const size_t smem = row_smem_bwdg(D);
+  const dim3 grid((S * H + ROW_LN_B - 1) / ROW_LN_B), block(64);
+  // the adjoint of `right` (2) walks w downwards, of `left` (3) upwards
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 2) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
+    else GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);          \
+  }
+  GA_ROW_DPLS(X)
+#undef X
+  return check_launch("sga row adjoint scan");
+}
+
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
              hipStream_t st)
 {
@@ -304,6 +333,9 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
 int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
               int N, int C, int D, int H, int W, int dir, hipStream_t st)
 {
+  if (rowwave_ok(D, W, dir, row_smem_bwdg(D)) && aligned16(g) && aligned16(gout) && aligned16(G) &&
+      (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0))
+    return row_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);

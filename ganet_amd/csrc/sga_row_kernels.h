@@ -24,6 +24,7 @@
 // Arithmetic order of the forward recurrence is identical to sga_kernels.h (bit-exact).
 #pragma once
 #include "ga_common.h"
+#include "sga_kernels.h"
 
 namespace ga {
 
@@ -172,6 +173,132 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
         if (pl < D && col_ok && rok[q])
           *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) =
               *reinterpret_cast<const f4 *>(at + (q * D + pl) * C::RS + 4 * piece);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- adjoint scan (backward step 1, see sga_kernels.h) with the same row staging --------------
+// grid.x = ceil(S*H / LN), block = 64.  desc: VISIT order w = W-1..0 (adjoint of `right`).
+// The G tile overwrites the gradOut tile in place (a lane rewrites exactly the cells it read).
+// dynamic LDS per image row: D*RS (gradOut -> G) + roundup4(D*(PP+1)) mask words + 5*SBH (w)
+// + SBH/2 words (kp as uint16).
+template <int DPL, int SBH, int PAD, int LN, bool desc>
+__global__ void __launch_bounds__(64)
+sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
+             const uint16_t *__restrict__ kp, const float *__restrict__ gout,
+             float *__restrict__ G, RowGeom geo, int dir)
+{
+  typedef RowCfg<SBH, PAD> C;
+  GA_DYN_SMEM(smem);
+  const int D = geo.D, W = geo.W;
+  const int total_rows = geo.total_rows;
+  constexpr int MS = C::PP + 1;
+  const int TS = D * C::RS;
+  const int MW = (D * MS + 3) & ~3;
+  float *gt = smem;                                            // [LN][D][RS]
+  uint32_t *mt = reinterpret_cast<uint32_t *>(gt + LN * TS);   // [LN][MW]
+  float *wt = reinterpret_cast<float *>(mt + LN * MW);         // [LN][5][SBH]
+  uint32_t *kt = reinterpret_cast<uint32_t *>(wt + LN * 5 * SBH);   // [LN][SBH/2]
+  const int lane = threadIdx.x;
+  const int rl = lane & 15;
+  const int r = (lane >> 4) % LN;
+  const bool owner = (lane >> 4) < LN;
+  LaneCtx c;
+  c.lg = rl; c.d0 = rl * DPL; c.line_ok = true; c.s = 0; c.q = 0;
+  const int piece = lane % C::PP, psub = lane / C::PP;
+  i64 vb[LN], gbo[LN], kbo[LN];
+  bool rok[LN];
+#pragma unroll
+  for (int q = 0; q < LN; q++) {
+    int row = blockIdx.x * LN + q;
+    rok[q] = row < total_rows;
+    if (!rok[q]) row = total_rows - 1;
+    const int s = row / geo.H, h = row - s * geo.H;
+    vb[q] = (i64)s * D * geo.HW + (i64)h * W;
+    gbo[q] = (i64)s * 5 * geo.HW + (i64)h * W;
+    kbo[q] = (i64)s * geo.HW + (i64)h * W;
+  }
+  const int nb = (W + SBH - 1) / SBH;
+  float Gn[DPL], wn[5], sgn = 0.f;
+#pragma unroll
+  for (int i = 0; i < DPL; i++) Gn[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 5; t++) wn[t] = 0.f;
+  float *gr = gt + r * TS;
+  const uint32_t *mr = mt + r * MW, *kr = kt + r * (SBH / 2);
+  const float *wr = wt + r * 5 * SBH;
+
+  for (int b = 0; b < nb; b++) {
+    const int w_lo = desc ? W - (b + 1) * SBH : b * SBH;
+    const int wq = w_lo + 4 * piece;
+    const bool col_ok = wq >= 0 && wq < W;
+#pragma unroll
+    for (int q = 0; q < LN; q++) {
+      for (int p0 = 0; p0 < D; p0 += C::PPI) {
+        const int pl = p0 + psub;
+        if (pl < D && col_ok) {
+          const i64 o = vb[q] + (i64)pl * geo.HW + wq;
+          *reinterpret_cast<f4 *>(gt + q * TS + pl * C::RS + 4 * piece) = *reinterpret_cast<const f4 *>(gout + o);
+          mt[q * MW + pl * MS + piece] = *reinterpret_cast<const uint32_t *>(mask + o);
+        }
+      }
+      if (psub < 5 && col_ok)
+        *reinterpret_cast<f4 *>(wt + (q * 5 + psub) * SBH + 4 * piece) =
+            *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)psub * geo.HW + wq);
+      if (psub == 5 && col_ok) {
+        const uint2 kk2 = *reinterpret_cast<const uint2 *>(kp + kbo[q] + wq);   // 4 x uint16
+        kt[q * (SBH / 2) + 2 * piece] = kk2.x;
+        kt[q * (SBH / 2) + 2 * piece + 1] = kk2.y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < C::PP; kq++) {
+      if (b * SBH + 4 * kq < W) {
+        const int cq = desc ? C::PP - 1 - kq : kq;
+        f4 gov[DPL], wv[5], ov[DPL];
+        uint32_t mw[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; i++) {
+          const int d = c.d0 + i < D ? c.d0 + i : D - 1;
+          gov[i] = *reinterpret_cast<const f4 *>(gr + d * C::RS + 4 * cq);
+          mw[i] = mr[d * MS + cq];
+        }
+#pragma unroll
+        for (int t = 0; t < 5; t++) wv[t] = *reinterpret_cast<const f4 *>(wr + t * SBH + 4 * cq);
+        const uint32_t k01 = kr[2 * cq], k23 = kr[2 * cq + 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int kk = desc ? 3 - k : k;
+          float go[DPL], w[5];
+          uint8_t mk[DPL];
+#pragma unroll
+          for (int i = 0; i < DPL; i++) {
+            go[i] = f4_get(gov[i], kk);
+            mk[i] = (uint8_t)(mw[i] >> (8 * kk));
+          }
+#pragma unroll
+          for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
+          const int kpv = (int)(((kk < 2 ? k01 : k23) >> (16 * (kk & 1))) & 0xffffu);
+          bwdg_step<16, DPL, uint8_t>(go, mk, Gn, wn, sgn, w, kpv, !(b == 0 && kq == 0 && k == 0), c, D, dir);
+#pragma unroll
+          for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < DPL; i++)
+          if (owner && c.d0 + i < D) *reinterpret_cast<f4 *>(gr + (c.d0 + i) * C::RS + 4 * cq) = ov[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LN; q++) {
+      for (int p0 = 0; p0 < D; p0 += C::PPI) {
+        const int pl = p0 + psub;
+        if (pl < D && col_ok && rok[q])
+          *reinterpret_cast<f4 *>(G + vb[q] + (i64)pl * geo.HW + wq) =
+              *reinterpret_cast<const f4 *>(gt + q * TS + pl * C::RS + 4 * piece);
       }
     }
     __syncthreads();

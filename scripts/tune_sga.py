@@ -16,7 +16,7 @@ lib = _native.lib()
 inp = bench.make_inputs(torch.device("cuda:0"))
 shape = os.environ.get("TUNE_SHAPE")
 rows = []
-for gd, bv, rw in itertools.product([4, 8], [64, 128, 256], [0, 1]):
+for gd, bv, rw in itertools.product([1, 2, 4], [64, 128, 256], [1]):
     lib.set_option("GANET_SGA_GD_V", gd)
     lib.set_option("GANET_SGA_GD_H", 16)
     lib.set_option("GANET_SGA_BLOCK_V", bv)
