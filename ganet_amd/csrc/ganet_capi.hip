@@ -254,7 +254,7 @@ size_t row_smem_fwd(int D)
 {
   return sizeof(float) * ROW_LN_F * ((size_t)2 * D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
 }
-constexpr int ROW_SBH_B = 16, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
+constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
 size_t row_smem_bwdg(int D)
 {
   const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH_B, ROW_PAD_B>::PP + 1) + 3) & ~(size_t)3;

@@ -61,7 +61,8 @@ template <int GD, int DPL> GA_DEV LaneCtx make_ctx(const ScanGeom &geo)
   const int tid = threadIdx.x;
   c.lg = tid % GD;
   c.d0 = c.lg * DPL;
-  int line = blockIdx.x * (blockDim.x / GD) + tid / GD;
+  // XCD-aware order: blocks that share cache lines (neighbouring column groups) stay on one XCD
+  int line = xcd_remap(blockIdx.x, gridDim.x) * (blockDim.x / GD) + tid / GD;
   c.line_ok = line < geo.total_lines;
   if (!c.line_ok) line = geo.total_lines - 1;
   c.s = line / geo.Q;
@@ -483,28 +484,48 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
       a_m[q] = 0.f;
       a_0[q] = pa.A[q][vb + poff[q]];
     }
-    for (int d = 0; d < D; d++) {
-      const i64 o = vb + (i64)d * HW;
-      const float xv = x[o];
-      float gxv = accumulate ? gradX[o] : 0.f;
+    // march over d in chunks of DU planes: all loads of a chunk are issued before any of them
+    // is consumed (one exposed memory latency per chunk instead of per plane; the first version
+    // ran at 2.9 TB/s with 65 dependent load->use round trips per lane)
+    constexpr int DU = 4;
+    for (int dc = 0; dc < D; dc += DU) {
+      float xv[DU], gxv[DU], Gv[DU][NDIR], Av[DU][NDIR];
 #pragma unroll
-      for (int q = 0; q < NDIR; q++) {
-        const float Gv = pa.G[q][o];
-        const float a_p = d + 1 < D ? pa.A[q][o + HW + poff[q]] : 0.f;   // A[pp][d+1]
-        float r = Gv * w0[q];
-        if (d == 0) r = fmaf(Gv, w2[q], r);
-        if (d == D - 1) r = fmaf(Gv, w3[q], r);
-        gxv += r;
-        s0[q] = fmaf(Gv, xv, s0[q]);
-        sg[q] += Gv;
-        s1[q] = fmaf(Gv, a_0[q], s1[q]);
-        s2[q] = fmaf(Gv, d >= 1 ? a_m[q] : xv, s2[q]);
-        s3[q] = fmaf(Gv, d + 1 < D ? a_p : xv, s3[q]);
-        mx[q] = fmaxf(mx[q], a_0[q]);
-        a_m[q] = a_0[q];
-        a_0[q] = a_p;
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u;
+        const i64 o = vb + (i64)(d < D ? d : D - 1) * HW;
+        xv[u] = x[o];
+        gxv[u] = accumulate ? gradX[o] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NDIR; q++) {
+          Gv[u][q] = pa.G[q][o];
+          Av[u][q] = d + 1 < D ? pa.A[q][o + HW + poff[q]] : 0.f;   // A[pp][d+1]
+        }
       }
-      gradX[o] = gxv;
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u;
+        if (d < D) {
+          float gacc = gxv[u];
+#pragma unroll
+          for (int q = 0; q < NDIR; q++) {
+            const float G_ = Gv[u][q], a_p = Av[u][q];
+            float r = G_ * w0[q];
+            if (d == 0) r = fmaf(G_, w2[q], r);
+            if (d == D - 1) r = fmaf(G_, w3[q], r);
+            gacc += r;
+            s0[q] = fmaf(G_, xv[u], s0[q]);
+            sg[q] += G_;
+            s1[q] = fmaf(G_, a_0[q], s1[q]);
+            s2[q] = fmaf(G_, d >= 1 ? a_m[q] : xv[u], s2[q]);
+            s3[q] = fmaf(G_, d + 1 < D ? a_p : xv[u], s3[q]);
+            mx[q] = fmaxf(mx[q], a_0[q]);
+            a_m[q] = a_0[q];
+            a_0[q] = a_p;
+          }
+          gradX[vb + (i64)d * HW] = gacc;
+        }
+      }
     }
 #pragma unroll
     for (int q = 0; q < NDIR; q++) {
