@@ -37,7 +37,8 @@ constexpr int LGA_TW = 32;   // tile width  (pixels, = lanes along W)
 constexpr int LGA_TH = 8;    // tile height
 constexpr int LGA_PB = 4;    // planes per LDS stage
 #ifndef LGA_WAVES_PER_SIMD
-#define LGA_WAVES_PER_SIMD 3   // register cap: the march is latency-bound, occupancy pays
+#define LGA_WAVES_PER_SIMD 3   // register cap for R <= 2: the march is latency-bound, occupancy pays
+                               // (R = 3 holds 147 taps per pixel: left uncapped so nothing spills)
 #endif
 
 // Aligned-window layout.  The tile's column halo is rounded up to an even width RE, so tile
@@ -118,7 +119,7 @@ GA_DEV void lga_stage_commit(float *__restrict__ buf, const float (&regs)[LgaCfg
 // ---- forward (TRANSPOSED = false) and data-backward (TRANSPOSED = true) ---------
 // y[b,d,i,j] = sum_t w_t * xs(d+dd, i+a, j+b)  with centre replacement.
 template <int R, bool TRANSPOSED>
-__global__ void __launch_bounds__(256, LGA_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
           LgaGeom geo)
 {
@@ -266,7 +267,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)
 template <int R>
-__global__ void __launch_bounds__(256, LGA_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
                 LgaGeom geo, int accumulate)
 {
