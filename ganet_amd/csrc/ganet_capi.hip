@@ -74,8 +74,6 @@ struct Options {
   int gd_h = 16;
   int streams = 0;
   int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
-  int lga_two = 1;      // LGA: two pixels per lane (lga2_kernels.h) when W is even
-  int lga_nsplit = 0;   // LGA forward: disparity splits per tile (0 = pick for CU balance)
   int block_v = 128;
   int block_h = 64;
 };
@@ -92,8 +90,6 @@ void load_env_options()
   geti("GANET_SGA_GD_H", g_opt.gd_h);
   geti("GANET_SGA_STREAMS", g_opt.streams);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
-  geti("GANET_LGA_TWO", g_opt.lga_two);
-  geti("GANET_LGA_NSPLIT", g_opt.lga_nsplit);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
   geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
@@ -460,8 +456,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
     if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
   } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_TWO")) g_opt.lga_two = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_NSPLIT")) g_opt.lga_nsplit = value < 0 ? 0 : value;
+
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);

@@ -453,11 +453,22 @@ struct PointArgs {
   int dir[4];
 };
 
+#ifndef GA_POINT_DU
+#define GA_POINT_DU 2
+#endif
+#ifndef GA_POINT_WAVES
+#define GA_POINT_WAVES 5
+#endif
 template <int NDIR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, GA_POINT_WAVES)
 sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa,
               int D, int H, int W, i64 npix, int accumulate)
 {
+  // Register diet: this kernel is pure load->use latency (91 % of wave time in s_waitcnt), so
+  // waves per SIMD is what counts.  Measured at cfg2: 127 VGPR / 4 waves 0.50 ms, 96 VGPR /
+  // 5 waves 0.39 ms; spilling to reach 6 waves loses again (0.43-0.62 ms), and so does fetching
+  // w2 / w3 only on the first / last plane.  Hence: 32-bit neighbour offsets, a bit mask for
+  // "has previous position", two planes in flight per step, capped at 5 waves per SIMD.
   const i64 HW = (i64)H * W;
   const i64 stride = (i64)gridDim.x * blockDim.x;
   for (i64 pidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
@@ -466,8 +477,8 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
     const i64 vb = s * D * HW + pix;
     const i64 gbo = s * 5 * HW + pix;
     float w0[NDIR], w2[NDIR], w3[NDIR];
-    bool hp[NDIR];
-    i64 poff[NDIR];
+    int poff[NDIR];          // previous position in forward order (0 = none, see hpm)
+    unsigned hpm = 0;        // bit q: direction q has a previous position at this pixel
     float s0[NDIR], s1[NDIR], s2[NDIR], s3[NDIR], sg[NDIR], mx[NDIR];
     float a_m[NDIR], a_0[NDIR];        // A[pp][d-1], A[pp][d]
 #pragma unroll
@@ -476,18 +487,16 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
       w0[q] = pa.g[q][gbo];
       w2[q] = pa.g[q][gbo + 2 * HW];
       w3[q] = pa.g[q][gbo + 3 * HW];
-      // previous position in forward order: down h-1, up h+1, right w-1, left w+1
-      hp[q] = dir == 0 ? h > 0 : dir == 1 ? h + 1 < H : dir == 2 ? w > 0 : w + 1 < W;
-      poff[q] = hp[q] ? (dir == 0 ? -(i64)W : dir == 1 ? (i64)W : dir == 2 ? -1 : 1) : 0;
+      // down: h-1, up: h+1, right: w-1, left: w+1
+      const bool hp = dir == 0 ? h > 0 : dir == 1 ? h + 1 < H : dir == 2 ? w > 0 : w + 1 < W;
+      poff[q] = hp ? (dir == 0 ? -W : dir == 1 ? W : dir == 2 ? -1 : 1) : 0;
+      hpm |= hp ? (1u << q) : 0u;
       s0[q] = s1[q] = s2[q] = s3[q] = sg[q] = 0.f;
       mx[q] = -INFINITY;
       a_m[q] = 0.f;
       a_0[q] = pa.A[q][vb + poff[q]];
     }
-    // march over d in chunks of DU planes: all loads of a chunk are issued before any of them
-    // is consumed (one exposed memory latency per chunk instead of per plane; the first version
-    // ran at 2.9 TB/s with 65 dependent load->use round trips per lane)
-    constexpr int DU = 4;
+    constexpr int DU = GA_POINT_DU;
     for (int dc = 0; dc < D; dc += DU) {
       float xv[DU], gxv[DU], Gv[DU][NDIR], Av[DU][NDIR];
 #pragma unroll
@@ -530,11 +539,12 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
 #pragma unroll
     for (int q = 0; q < NDIR; q++) {
       float *gw = pa.gw[q] + gbo;
+      const bool hp = (hpm >> q) & 1u;
       gw[0] = s0[q];
-      gw[HW] = hp[q] ? s1[q] : 0.f;
-      gw[2 * HW] = hp[q] ? s2[q] : 0.f;
-      gw[3 * HW] = hp[q] ? s3[q] : 0.f;
-      gw[4 * HW] = hp[q] ? sg[q] * mx[q] : 0.f;
+      gw[HW] = hp ? s1[q] : 0.f;
+      gw[2 * HW] = hp ? s2[q] : 0.f;
+      gw[3 * HW] = hp ? s3[q] : 0.f;
+      gw[4 * HW] = hp ? sg[q] * mx[q] : 0.f;
     }
   }
 }

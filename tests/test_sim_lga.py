@@ -25,15 +25,11 @@ def test_lga_chain_matches_golden(sim, name):
     assert max(err.values()) < 2e-5, err
 
 
-@pytest.mark.parametrize("two,nsplit", [(0, 0), (1, 0), (1, 1), (1, 3)])
 @pytest.mark.parametrize("shape,r", [((1, 9, 10, 34), 2), ((2, 5, 17, 33), 2), ((1, 4, 9, 40), 1),
                                      ((1, 6, 3, 70), 3), ((1, 1, 8, 32), 2), ((1, 13, 16, 64), 2),
                                      ((1, 50, 5, 66), 2), ((1, 2, 2, 2), 2)])
-def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r, two, nsplit):
-    """Shapes that cross tile borders and LDS stage boundaries, for the one-pixel-per-lane kernels
-    (odd widths always use them) and the two-pixels-per-lane kernels with / without disparity splits."""
-    sim.set_option("GANET_LGA_TWO", two)
-    sim.set_option("GANET_LGA_NSPLIT", nsplit)
+def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
+    """Shapes that cross tile borders and LDS stage boundaries, odd and even widths (both window parities)."""
     rng = np.random.default_rng(sum(shape) + r)
     fs = list(shape)
     fs[1] = 3 * (2 * r + 1) ** 2
@@ -42,11 +38,7 @@ def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r, two, nsplit):
     gy = rng.standard_normal(shape).astype(np.float32)
     y = port_oracle.lga_forward(x, f, r)
     gx, gf = port_oracle.lga_backward(x, f, gy, r)
-    try:
-        err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
-    finally:
-        sim.set_option("GANET_LGA_TWO", 1)
-        sim.set_option("GANET_LGA_NSPLIT", 0)
+    err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
     assert max(err.values()) < 2e-5, err
 
 
