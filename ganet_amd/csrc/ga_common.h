@@ -178,54 +178,6 @@ template <int GD> GA_DEV int seg_allmin_i(int v)
   return v;
 }
 
-// ---- whole-wave (64-lane) ops for kernels where ONE scanline owns the wavefront -------
-// arbitrary-lane read through the LDS crossbar (ds_bpermute_b32: no LDS memory touched)
-GA_DEV int wave_read_i(int src_lane, int v)
-{
-#if defined(GA_HIPSIM)
-  return hipsim::bpermute(src_lane, v);
-#else
-  return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
-#endif
-}
-GA_DEV float wave_read_f(int src_lane, float v) { return i2f(wave_read_i(src_lane, f2i(v))); }
-// value of lane-1 / lane+1; the first / last lane keeps `old`
-GA_DEV float wave_from_prev(float old, float src, int lane)
-{
-  const float r = wave_read_f(lane > 0 ? lane - 1 : 0, src);
-  return lane == 0 ? old : r;
-}
-GA_DEV float wave_from_next(float old, float src, int lane)
-{
-  const float r = wave_read_f(lane < 63 ? lane + 1 : 63, src);
-  return lane == 63 ? old : r;
-}
-GA_DEV float wave_allmax(float v, int lane)
-{
-  v = seg_allmax<16>(v);
-  v = fmaxf(v, wave_read_f(lane ^ 16, v));
-  v = fmaxf(v, wave_read_f(lane ^ 32, v));
-  return v;
-}
-GA_DEV float wave_allsum(float v, int lane)
-{
-  v = seg_allsum<16>(v);
-  v += wave_read_f(lane ^ 16, v);
-  v += wave_read_f(lane ^ 32, v);
-  return v;
-}
-GA_DEV int wave_allmin_i(int v, int lane)
-{
-  int o;
-  o = dpp_i<DPP_QP_XOR1>(v, v); v = o < v ? o : v;
-  o = dpp_i<DPP_QP_XOR2>(v, v); v = o < v ? o : v;
-  o = dpp_i<DPP_ROW_HALF_MIRROR>(v, v); v = o < v ? o : v;
-  o = dpp_i<DPP_ROW_MIRROR>(v, v); v = o < v ? o : v;
-  o = wave_read_i(lane ^ 16, v); v = o < v ? o : v;
-  o = wave_read_i(lane ^ 32, v); v = o < v ? o : v;
-  return v;
-}
-
 // MI355X: workgroup b runs on XCD b % 8 (observed, speed only).  Give each XCD a
 // contiguous range of logical blocks so neighbouring tiles share one L2.
 GA_DEV int xcd_remap(int b, int nb)

@@ -6,6 +6,7 @@
 #include "misc_kernels.h"
 #include "sga_kernels.h"
 #include "sga_row_kernels.h"
+#include "sga_col_kernels.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -74,6 +75,7 @@ struct Options {
   int gd_h = 16;
   int streams = 0;
   int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
+  int colblock = 1;     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
   int block_v = 128;
   int block_h = 64;
 };
@@ -90,6 +92,7 @@ void load_env_options()
   geti("GANET_SGA_GD_H", g_opt.gd_h);
   geti("GANET_SGA_STREAMS", g_opt.streams);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
+  geti("GANET_SGA_COLBLOCK", g_opt.colblock);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
   geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
@@ -243,12 +246,12 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
 
 // ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
 // rows per wavefront (LN) x positions per staged batch (SBH): LDS per wave bounds residency
-constexpr int ROW_SBH_F = 16, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: 2 tiles per row  (10.7 KB per row at D=65)
+constexpr int ROW_SBH_F = 32, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: 2 tiles per row  (10.7 KB per row at D=65)
 constexpr size_t ROW_SMEM_MAX = 64 * 1024;
 
 size_t row_smem_fwd(int D)
 {
-  return sizeof(float) * ROW_LN_F * ((size_t)2 * D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
+  return sizeof(float) * ROW_LN_F * ((size_t)D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
 }
 constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
 size_t row_smem_bwdg(int D)
@@ -292,6 +295,54 @@ int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
   return check_launch("sga row forward");
 }
 
+// ---- vertical scans over LDS-staged 16-column blocks (sga_col_kernels.h) ----------------------------
+size_t col_smem_fwd(int D) { return sizeof(float) * ((size_t)2 * COL_NC * D * COL_SBV + COL_NC * 5 * COL_SBV); }
+size_t col_smem_bwdg(int D)
+{
+  return sizeof(float) * ((size_t)COL_NC * D * COL_SBV + COL_NC * 5 * COL_SBV + COL_NC * COL_SBV) +
+         (size_t)D * COL_SBV * 16;
+}
+bool colblock_ok(int D, int W, int dir, size_t smem)
+{
+  return opts().colblock && dir < 2 && W % 4 == 0 && D <= 16 * 13 && smem <= ROW_SMEM_MAX;
+}
+
+int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  ColGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const int dpl = row_dpl(D);
+  const size_t smem = col_smem_fwd(D);
+  const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 0) GA_LAUNCH_SMEM((sga_col_fwd<P, true>), grid, block, smem, st, x, g, A, geo);      \
+    else GA_LAUNCH_SMEM((sga_col_fwd<P, false>), grid, block, smem, st, x, g, A, geo);              \
+  }
+  GA_ROW_DPLS(X)
+#undef X
+  return check_launch("sga column-block forward");
+}
+
+int col_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
+             int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  ColGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  const int dpl = row_dpl(D);
+  const size_t smem = col_smem_bwdg(D);
+  const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
+  // the adjoint of `down` (0) walks rows upwards (H-1..0), of `up` (1) downwards
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 1) GA_LAUNCH_SMEM((sga_col_bwdg<P, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
+    else GA_LAUNCH_SMEM((sga_col_bwdg<P, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);          \
+  }
+  GA_ROW_DPLS(X)
+#undef X
+  return check_launch("sga column-block adjoint scan");
+}
+
 int row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
              int S, int D, int H, int W, int dir, hipStream_t st)
 {
@@ -316,6 +367,8 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
 {
   if (rowwave_ok(D, W, dir, row_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A))
     return row_fwd(x, g, A, N * C, D, H, W, dir, st);
+  if (colblock_ok(D, W, dir, col_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A) && N * C <= 65535)
+    return col_fwd(x, g, A, N * C, D, H, W, dir, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
@@ -332,6 +385,9 @@ int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const flo
   if (rowwave_ok(D, W, dir, row_smem_bwdg(D)) && aligned16(g) && aligned16(gout) && aligned16(G) &&
       (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0))
     return row_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
+  if (colblock_ok(D, W, dir, col_smem_bwdg(D)) && aligned16(g) && aligned16(gout) && aligned16(G) &&
+      (((uintptr_t)mask & 3) == 0) && N * C <= 65535)
+    return col_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
@@ -456,6 +512,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
     if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
   } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
 
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;

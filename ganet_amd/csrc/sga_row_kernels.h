@@ -81,7 +81,7 @@ GA_DEV void fwd_row_step(const float (&xs)[DPL], const float (&w)[5], float (&A)
 
 // grid.x = ceil(S*H / LN), block = 64: DPP row r of the wave owns image row blockIdx.x*LN + r
 // (rows >= LN mirror row r % LN).  desc: visit w = W-1 .. 0 (direction `left`).
-// dynamic LDS: LN * (2*D*RS + 5*SBH) floats.
+// dynamic LDS: LN * (D*RS + 5*SBH) floats (the A tile aliases the x tile).
 template <int DPL, int SBH, int PAD, int LN, bool desc>
 __global__ void __launch_bounds__(64)
 sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ A,
@@ -92,8 +92,9 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   const int D = geo.D, W = geo.W;
   const int total_rows = geo.total_rows;
   float *xt = smem;                       // [LN][D][RS]
-  float *at = xt + LN * D * C::RS;        // [LN][D][RS]
-  float *wt = at + LN * D * C::RS;        // [LN][5][SBH]
+  float *at = xt;                         // A overwrites the x tile in place (a lane rewrites
+                                          // exactly the cells it read; mirror rows do not write)
+  float *wt = xt + LN * D * C::RS;        // [LN][5][SBH]
   const int lane = threadIdx.x;
   const int rl = lane & 15;
   const int r = (lane >> 4) % LN;

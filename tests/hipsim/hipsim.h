@@ -37,6 +37,7 @@ struct dim3 {
 };
 
 struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
@@ -111,20 +112,6 @@ inline int update_dpp(int old, int src, int ctrl)
   else { fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
   if (valid && sl >= wsize) valid = false;   // inactive source lane: dest keeps old
   const int v = valid ? s.xchg[wave * 64 + sl] : old;
-  barrier_wait(s.wave_bar[wave], wsize);
-  return v;
-}
-
-// ds_bpermute_b32: every lane reads `src` of lane `src_lane` (mod 64) of its wave
-inline int bpermute(int src_lane, int src)
-{
-  State &s = S();
-  const int tid = flat_tid(), wave = tid >> 6;
-  const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
-  s.xchg[tid] = src;
-  barrier_wait(s.wave_bar[wave], wsize);
-  const int sl = src_lane & 63;
-  const int v = sl < wsize ? s.xchg[wave * 64 + sl] : 0;
   barrier_wait(s.wave_bar[wave], wsize);
   return v;
 }

@@ -85,6 +85,20 @@ def test_horizontal_kernel_families(sim, port_oracle, shape, rowwave):
         sim.set_option("GANET_SGA_ROWWAVE", 1)
 
 
+@pytest.mark.parametrize("colblock", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 2, 6, 3, 4), (2, 1, 20, 9, 20), (1, 1, 65, 5, 36), (1, 1, 130, 2, 8), (1, 2, 33, 13, 48)])
+def test_vertical_kernel_families(sim, port_oracle, shape, colblock):
+    """Register-only segment scans vs LDS-staged 16-column blocks (down / up), incl. partial
+    column blocks, H not a multiple of the 4-row batch and D > 64."""
+    sim.set_option("GANET_SGA_COLBLOCK", colblock)
+    try:
+        x, gs, go = pc.sga_inputs(shape, seed=31 + colblock)
+        err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_SGA_COLBLOCK", 1)
+
+
 def test_dpp_selftest(sim):
     scratch = np.zeros(8 * 64, np.int32)
     host = np.zeros(8 * 64, np.int32)
