@@ -105,7 +105,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   bool rok[LN];
 #pragma unroll
   for (int q = 0; q < LN; q++) {
-    int row = blockIdx.x * LN + q;
+    int row = xcd_remap(blockIdx.x, gridDim.x) * LN + q;   // neighbouring rows share lines at their ends
     rok[q] = row < total_rows;
     if (!rok[q]) row = total_rows - 1;
     const int s = row / geo.H, h = row - s * geo.H;
@@ -213,7 +213,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   bool rok[LN];
 #pragma unroll
   for (int q = 0; q < LN; q++) {
-    int row = blockIdx.x * LN + q;
+    int row = xcd_remap(blockIdx.x, gridDim.x) * LN + q;   // neighbouring rows share lines at their ends
     rok[q] = row < total_rows;
     if (!rok[q]) row = total_rows - 1;
     const int s = row / geo.H, h = row - s * geo.H;
