@@ -201,6 +201,49 @@ def test_full_size_properties(api, dev):
     assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
 
 
+@pytest.mark.parametrize("shape", [(1, 48, 33, 40, 104), (2, 32, 65, 176, 320), (1, 32, 65, 128, 416)])
+def test_sga_model_shapes_fast_path_vs_compat_path(api, dev, shape):
+    """The other SGA shapes of BASELINE configs 2-5 (1/6-resolution volumes, SceneFlow 960x528 at
+    2 samples per GPU, KITTI 1248x384): the fast path (column-block / row-per-wave kernels, uint8
+    mask, saved volumes) and the reference-buffer-contract path (segment scans, float mask,
+    recomputed volumes) are different kernel families and must agree -- forward bit-exact,
+    gradients to fp32 rounding -- with no oracle in the loop."""
+    torch = dev.torch
+    N, C, D, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(shape, device="cuda", generator=g)
+    gs = [torch.nn.functional.normalize(torch.randn((N, C, 5, H, W), device="cuda", generator=g), p=1, dim=2)
+          for _ in range(4)]
+    go = torch.randn(shape, device="cuda", generator=g)
+    st = dev.stream
+    A = torch.empty((4,) + shape, device="cuda")
+    out, gx = torch.empty_like(x), torch.empty_like(x)
+    mask = torch.empty(shape, dtype=torch.uint8, device="cuda")
+    kp = torch.empty((4, N, C, H, W), dtype=torch.int16, device="cuda")
+    gw = [torch.empty_like(t) for t in gs]
+    api.call("ganet_sga_forward", x.data_ptr(), *[t.data_ptr() for t in gs], A.data_ptr(), out.data_ptr(),
+             mask.data_ptr(), kp.data_ptr(), N, C, D, H, W, st)
+    G = torch.empty_like(A)
+    api.call("ganet_sga_backward", x.data_ptr(), *[t.data_ptr() for t in gs], A.data_ptr(), mask.data_ptr(),
+             kp.data_ptr(), go.data_ptr(), G.data_ptr(), gx.data_ptr(), *[t.data_ptr() for t in gw], N, C, D, H, W, st)
+    del G
+    tmp, out2, maskf = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+    api.call("ganet_sga_forward_compat", x.data_ptr(), *[t.data_ptr() for t in gs], tmp.data_ptr(), out2.data_ptr(),
+             maskf.data_ptr(), N, C, D, H, W, st)
+    assert torch.equal(out, out2) and torch.equal(mask.float(), maskf) and torch.equal(tmp, A[3])
+    gx2 = torch.zeros_like(x)
+    gw2 = [torch.zeros_like(t) for t in gs]
+    tgrad = torch.empty_like(x)
+    idx = torch.empty((N, C, H, W), device="cuda")
+    api.call("ganet_sga_backward_compat", x.data_ptr(), *[t.data_ptr() for t in gs], tmp.data_ptr(), maskf.data_ptr(),
+             idx.data_ptr(), go.data_ptr(), tgrad.data_ptr(), gx2.data_ptr(), *[t.data_ptr() for t in gw2],
+             N, C, D, H, W, st)
+    torch.cuda.synchronize()
+    assert (gx - gx2).abs().max().item() <= pc.TOL
+    for a, b in zip(gw, gw2):
+        assert (a - b).abs().max().item() <= pc.TOL
+
+
 def test_cost_volume_and_regression(api, dev, port_oracle):
     torch = dev.torch
     rng = np.random.default_rng(11)
