@@ -90,5 +90,12 @@ def lib():
     if _LIB is None:
         with _LOCK:
             if _LIB is None:
+                # The library links libamdhip64 by SONAME; PyTorch-ROCm ships its own copy.  Whichever is
+                # mapped first serves both, so torch must come first: otherwise the process holds two HIP
+                # runtimes and launches on torch-allocated memory fail with hipErrorNoDevice.
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
                 _LIB = CApi(lib_path())
     return _LIB

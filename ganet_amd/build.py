@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["ganet_capi.hip"]
-HEADERS = ["ga_common.h", "sga_kernels.h", "lga_kernels.h", "misc_kernels.h"]
+HEADERS = ["ga_common.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "lga_kernels.h", "misc_kernels.h"]
 OUT = os.path.join(_HERE, "libganet_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
 

@@ -24,10 +24,12 @@
   hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 #define GA_EXPORT extern "C"
 #else
+// hipGetLastError() is per-thread state shared with the host framework: drop whatever an earlier,
+// unrelated HIP call left there so check_launch() reports THIS launch
 #define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
 #define GA_EXPORT extern "C" __attribute__((visibility("default")))
 #endif
 

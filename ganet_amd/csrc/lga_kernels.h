@@ -226,12 +226,12 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
   for (int c = 0; c < nchunks; c++) {
     const bool more = c + 1 < nchunks;
     if (more) lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);
-    const float *buf = tile[c & 1];
+    const lds_cptr buf = GA_LDS_CPTR(&tile[0][0]) + (c & 1) * C::STAGE;
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
       const int d = c * LGA_PB + pl;
       if (d < geo.D) {
-        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
+        const lds_cptr pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
         // four independent accumulator chains (a single chain of dependent v_pk_fma_f32 was
         // slower than three scalar chains; 15 chains cost registers -> occupancy)
         f2 s_x = mk2(0.f, 0.f), s_y = mk2(0.f, 0.f), s_p0 = mk2(0.f, 0.f), s_p1 = mk2(0.f, 0.f);
@@ -240,7 +240,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
         for (int a = 0; a < C::WS; a++) {
 #pragma unroll
           for (int q = 0; q < C::NP; q++) {
-            const f2 vv = *reinterpret_cast<const f2 *>(pb + a * C::TW2 + 2 * q);
+            const f2 vv = lds_read_b64(pb + a * C::TW2 + 2 * q);
             s_x = fma2(mk2(vv.x, vv.x), wab[a][2 * q], s_x);
             s_y = fma2(mk2(vv.y, vv.y), wab[a][2 * q + 1], s_y);
             if (a & 1) s_p1 = fma2(vv, wc[a][q], s_p1);
@@ -353,13 +353,13 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
       const int dn = (c + 1) * LGA_PB + pl + 1;
       gnext[pl] = dn < geo.D ? gyb[(i64)dn * geo.HW + pix] : 0.f;
     }
-    const float *buf = tile[c & 1];
+    const lds_cptr buf = GA_LDS_CPTR(&tile[0][0]) + (c & 1) * C::STAGE;
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
       const int d = c * LGA_PB + pl;
       if (d < geo.D) {
         const float g_p = gcur[pl];                       // gy[d+1] (0 past the end)
-        const float *pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
+        const lds_cptr pb = buf + pl * C::PLANE + ty * C::TW2 + rcol;
         // plane d pairs with gy[d+1] for slab -1, gy[d] for slab 0, gy[d-1] for slab +1
         const f2 g01 = mk2(g_p, g_0), gmm = mk2(g_m, g_m);
         float xc = 0.f;
@@ -367,7 +367,7 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
         for (int a = 0; a < C::WS; a++) {
 #pragma unroll
           for (int q = 0; q < C::NP; q++) {
-            const f2 vv = *reinterpret_cast<const f2 *>(pb + a * C::TW2 + 2 * q);
+            const f2 vv = lds_read_b64(pb + a * C::TW2 + 2 * q);
             sab[a][2 * q] = fma2(mk2(vv.x, vv.x), g01, sab[a][2 * q]);
             sab[a][2 * q + 1] = fma2(mk2(vv.y, vv.y), g01, sab[a][2 * q + 1]);
             sc[a][q] = fma2(vv, gmm, sc[a][q]);
