@@ -8,7 +8,11 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["ganet_capi.hip"]
 HEADERS = ["ga_common.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "lga_kernels.h", "misc_kernels.h"]
 OUT = os.path.join(_HERE, "libganet_hip.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
+# -fno-slp-vectorize: hipcc otherwise packs neighbouring scalar FMAs of the scan recurrences into
+# v_pk_fma_f32 and pays for it in v_mov shuffles (12 per scan position); where packing helps (LGA) the
+# kernels use explicit 2-vectors, which this flag does not touch
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+               "-fno-slp-vectorize"]
 
 
 def _stale(out, deps):

@@ -41,11 +41,24 @@ extern __shared__ __attribute__((aligned(16))) float ga_dyn_smem_raw[];
 #if defined(GA_HIPSIM)
 struct f2 { float x, y; };
 GA_DEV f2 fma2(f2 a, f2 b, f2 c) { f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
+GA_DEV f2 add2(f2 a, f2 b) { f2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
 #else
 typedef float f2 __attribute__((ext_vector_type(2)));
 GA_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+GA_DEV f2 add2(f2 a, f2 b) { return a + b; }
 #endif
 GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+// optimisation fence on a packed value: it has to be complete HERE (no sinking into a later branch)
+#if defined(GA_HIPSIM)
+#define GA_KEEP_F2(v) ((void)0)
+#define GA_OPAQUE_S(v) ((void)0)
+#define GA_SCHED_FENCE() ((void)0)
+#else
+#define GA_KEEP_F2(v) asm volatile("" : "+v"(v))
+#define GA_OPAQUE_S(v) asm volatile("" : "+s"(v))   // uniform value the optimiser may not reason about
+// nothing is scheduled across this point: used to pin a hand-chosen instruction interleaving
+#define GA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // one 8-byte LDS read that stays a ds_read_b64 (256 B/clk/CU): left alone, the compiler fuses
 // neighbouring pairs into ds_read2_b64, which the LDS serves at half that rate
 // (MI355X_MICROARCH.md, LDS table).  volatile = "do not merge"; it adds no waits.  The pointer
@@ -78,6 +91,15 @@ GA_DEV int lane_id()
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 #endif
 }
+
+// hand-off between the lanes of ONE wavefront through LDS (kernels whose workgroup is a single wave)
+#if defined(GA_HIPSIM)
+#define GA_WAVE_SYNC() __syncthreads()     // emulator: the block IS one wave in these kernels
+#else
+// no instruction: the lanes of a wave run in lockstep and its LDS queue is in order; this only
+// stops the compiler from moving LDS accesses across the hand-off
+#define GA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 
 // ---- DPP (data-parallel primitives) ---------------------------------------
 // dpp_ctrl encodings (LLVM SIDefines.h DppCtrl): quad_perm 0x00-0xFF,
@@ -143,20 +165,45 @@ template <int GD> GA_DEV float seg_from_prev(float old, float src, int lg)
 {
   if (GD == 1) return old;
   const float r = dpp_f<DPP_ROW_SHR1>(old, src);
+  if (GD == 16) return r;          // a 16-lane segment IS a DPP row: its lane 0 has no source and keeps `old`
   return lg == 0 ? old : r;
 }
 template <int GD> GA_DEV float seg_from_next(float old, float src, int lg)
 {
   if (GD == 1) return old;
   const float r = dpp_f<DPP_ROW_SHL1>(old, src);
+  if (GD == 16) return r;
   return lg == GD - 1 ? old : r;
 }
+// max of two values that are known not to be signalling NaNs (results of arithmetic): fmaxf()
+// makes hipcc canonicalise each operand first (an extra v_max_f32 x, x per element)
+GA_DEV float vmax_raw(float a, float b)
+{
+#if defined(GA_HIPSIM)
+  return fmaxf(a, b);
+#else
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+// all-lanes max over the segment.  On the GPU this is written out as v_max_f32_dpp: from
+// fmaxf(v, dpp(v)) hipcc makes v_mov_b32_dpp + v_max_f32 x, x (quieting a possible signalling NaN of
+// the moved bits) + v_max_f32, three instructions per butterfly step on the serial path of every scan
+// position.  (s_nop 1: a DPP read needs two wait states after the VALU write of its source.)
 template <int GD> GA_DEV float seg_allmax(float v)
 {
+#if defined(GA_HIPSIM) || defined(GA_NO_DPP)
   if (GD >= 2) v = fmaxf(v, dpp_perm_f<DPP_QP_XOR1>(v));
   if (GD >= 4) v = fmaxf(v, dpp_perm_f<DPP_QP_XOR2>(v));
   if (GD >= 8) v = fmaxf(v, dpp_perm_f<DPP_ROW_HALF_MIRROR>(v));
   if (GD >= 16) v = fmaxf(v, dpp_perm_f<DPP_ROW_MIRROR>(v));
+#else
+  if (GD >= 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+  if (GD >= 4) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+  if (GD >= 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+  if (GD >= 16) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+#endif
   return v;
 }
 template <int GD> GA_DEV float seg_allsum(float v)

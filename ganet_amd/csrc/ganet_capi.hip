@@ -76,6 +76,8 @@ struct Options {
   int gd_v = 4;
   int gd_h = 16;
   int streams = 0;
+  int lga_wave = 2;   // LGA forward / data-backward: 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  int lga_segs = 0;   // depth segments per tile for those kernels (0 = automatic)
   int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
   int colblock = 1;     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
   int block_v = 128;
@@ -93,6 +95,8 @@ void load_env_options()
   geti("GANET_SGA_GD_V", g_opt.gd_v);
   geti("GANET_SGA_GD_H", g_opt.gd_h);
   geti("GANET_SGA_STREAMS", g_opt.streams);
+  geti("GANET_LGA_WAVE", g_opt.lga_wave);
+  geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
@@ -285,12 +289,15 @@ int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
   RowGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
   const int dpl = row_dpl(D);
+  const bool full = dpl > 0 && D % dpl == 0;     // lanes wholly inside / outside [0, D): leaner recurrence
   const size_t smem = row_smem_fwd(D);
   const dim3 grid((S * H + ROW_LN_F - 1) / ROW_LN_F), block(64);
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
-    if (dir == 3) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true>), grid, block, smem, st, x, g, A, geo);  \
-    else GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false>), grid, block, smem, st, x, g, A, geo);          \
+    if (dir == 3 && full) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true, true>), grid, block, smem, st, x, g, A, geo);  \
+    else if (dir == 3) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true, false>), grid, block, smem, st, x, g, A, geo);  \
+    else if (full) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false, true>), grid, block, smem, st, x, g, A, geo);      \
+    else GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false, false>), grid, block, smem, st, x, g, A, geo);               \
   }
   GA_ROW_DPLS(X)
 #undef X
@@ -314,12 +321,15 @@ int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
   ColGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   const int dpl = row_dpl(D);
+  const bool full = dpl > 0 && D % dpl == 0;
   const size_t smem = col_smem_fwd(D);
   const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
-    if (dir == 0) GA_LAUNCH_SMEM((sga_col_fwd<P, true>), grid, block, smem, st, x, g, A, geo);      \
-    else GA_LAUNCH_SMEM((sga_col_fwd<P, false>), grid, block, smem, st, x, g, A, geo);              \
+    if (dir == 0 && full) GA_LAUNCH_SMEM((sga_col_fwd<P, true, true>), grid, block, smem, st, x, g, A, geo);      \
+    else if (dir == 0) GA_LAUNCH_SMEM((sga_col_fwd<P, true, false>), grid, block, smem, st, x, g, A, geo);        \
+    else if (full) GA_LAUNCH_SMEM((sga_col_fwd<P, false, true>), grid, block, smem, st, x, g, A, geo);            \
+    else GA_LAUNCH_SMEM((sga_col_fwd<P, false, false>), grid, block, smem, st, x, g, A, geo);                     \
   }
   GA_ROW_DPLS(X)
 #undef X
@@ -442,17 +452,56 @@ int ew_grid(i64 n)
 }
 
 // ---- LGA dispatch -------------------------------------------------------------------
+// depth segments per tile for the wave-autonomous LGA kernels: enough work items (~7 per SIMD) for
+// the dispatcher to balance 1,024 SIMDs, segments no shorter than 32 planes (each item re-gathers
+// its pixel's filter taps and reads two extra halo planes)
+int lga_segments(int tiles, int D)
+{
+  int nseg = opts().lga_segs;
+  if (nseg <= 0) {
+    nseg = (7 * 1024 + tiles - 1) / tiles;
+    const int cap = D / 32 > 1 ? D / 32 : 1;
+    if (nseg > cap) nseg = cap;
+  }
+  if (nseg > D) nseg = D;
+  if (nseg < 1) nseg = 1;
+  return nseg;
+}
+
 template <int R>
 int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H, int W,
                    bool transposed, hipStream_t st)
 {
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  if (opts().lga_wave && W % 2 == 0 && ((uintptr_t)x & 7) == 0 && (i64)H * W < (1ll << 31)) {
+    LgaSeg sg;
+    sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+    sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+    const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
+    sg.nseg = lga_segments((int)(tiles < (1 << 30) ? tiles : (1 << 30)), D);
+    sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
+    sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
+    const i64 items = tiles * sg.nseg;
+    if constexpr (LgaDCfg<R>::OK) {
+      if (items < (1ll << 31) && opts().lga_wave == 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0) {
+        if (transposed) GA_LAUNCH((lga_apply_dma<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+        else GA_LAUNCH((lga_apply_dma<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+        return check_launch("lga apply (dma)");
+      }
+    }
+    if (items < (1ll << 31)) {
+      if (transposed) GA_LAUNCH((lga_apply_wave<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+      else GA_LAUNCH((lga_apply_wave<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+      return check_launch("lga apply (wave)");
+    }
+  }
   const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
   if (transposed) GA_LAUNCH((lga_apply<R, true>), grid, dim3(256), st, x, f, y, geo);
   else GA_LAUNCH((lga_apply<R, false>), grid, dim3(256), st, x, f, y, geo);
   return check_launch("lga apply");
 }
+
 template <int R>
 int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc,
                   hipStream_t st)
@@ -513,6 +562,8 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
     if (strcmp(name, "GANET_SGA_GD_H")) g_opt.gd_v = value;
     if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
   } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
 

@@ -31,7 +31,7 @@ constexpr int COL_NC = 16;     // columns per block
 // grid = (ceil(W/16), S), block = 256.  asc: visit rows 0..H-1 (down), else H-1..0 (up).
 // Requires W % 4 == 0 and 16-byte aligned bases.
 // dynamic LDS floats: 2 * 16*D*4 (x tile, A tile) + 16*5*4 (guidance).
-template <int DPL, bool asc>
+template <int DPL, bool asc, bool FULL>
 __global__ void __launch_bounds__(256)
 sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ A,
             ColGeom geo)
@@ -55,7 +55,7 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   const int lane = tid & 63, wv = tid >> 6;
   const int cidx = wv * 4 + (lane >> 4);
   LaneCtx c;
-  c.lg = lane & 15; c.d0 = c.lg * DPL; c.line_ok = c0 + cidx < W; c.s = 0; c.q = 0;
+  c.lg = lane & 15; c.d0 = c.lg * DPL; c.line_ok = c0 + cidx < W; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   // copy role: piece = 4 columns (16 B), seg = (plane, row-in-batch)
   const int piece = tid & 3, seg0 = tid >> 2;
   const bool pcol_ok = c0 + 4 * piece < W;
@@ -130,7 +130,7 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
           for (int i = 0; i < DPL; i++) xs[i] = f4_get(xv[i], k);
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv4[t], k);
-          fwd_step<16, DPL>(xs, w, Ap, m, b == 0 && k == 0, c, D);
+          fwd_step<16, DPL, FULL>(xs, w, Ap, m, b == 0 && k == 0, c, D);
         }
 #pragma unroll
         for (int i = 0; i < DPL; i++) f4_set(ov[i], k, Ap[i]);
@@ -192,7 +192,7 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   const int lane = tid & 63, wv = tid >> 6;
   const int cidx = wv * 4 + (lane >> 4);
   LaneCtx c;
-  c.lg = lane & 15; c.d0 = c.lg * DPL; c.line_ok = c0 + cidx < W; c.s = 0; c.q = 0;
+  c.lg = lane & 15; c.d0 = c.lg * DPL; c.line_ok = c0 + cidx < W; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   const int piece = tid & 3, seg0 = tid >> 2;
   const bool pcol_ok = c0 + 4 * piece < W;
   const int nseg = D * SB;

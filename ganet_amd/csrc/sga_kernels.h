@@ -53,7 +53,21 @@ struct LaneCtx {
   int d0;        // first disparity owned
   bool line_ok;  // scanline exists (else the lane shadows the last line, no stores)
   int s, q;      // slice, scanline within slice
+  float cap;     // +inf if the lane's first disparity is inside [0, D), else -inf (see lane_cap)
 };
+
+// The running max of a lane that lies outside the disparity range is neutralised with
+// fminf(max, cap).  The value is made opaque on purpose: written as a select on (d0 < D), hipcc
+// turns it back into select(max, -inf) and then quiets every operand of the cross-lane
+// reduction that follows (v_max_f32 x, x: 8 extra instructions per scan position).
+GA_DEV float lane_cap(int d0, int D)
+{
+  float cap = d0 < D ? INFINITY : -INFINITY;
+#if !defined(GA_HIPSIM)
+  asm volatile("" : "+v"(cap));
+#endif
+  return cap;
+}
 
 template <int GD, int DPL> GA_DEV LaneCtx make_ctx(const ScanGeom &geo)
 {
@@ -67,16 +81,22 @@ template <int GD, int DPL> GA_DEV LaneCtx make_ctx(const ScanGeom &geo)
   if (!c.line_ok) line = geo.total_lines - 1;
   c.s = line / geo.Q;
   c.q = line - c.s * geo.Q;
+  c.cap = lane_cap(c.d0, geo.D);
   return c;
 }
 
 // ---- forward recurrence, one position ------------------------------------------
 // Aprev/mprev: directional volume and its max over d at the previous position.
-template <int GD, int DPL>
+// FULL: the caller guarantees D % DPL == 0 (e.g. 65 = 13 x 5), so every lane lies wholly inside or
+// wholly outside [0, D) and the per-element range tests collapse to two per-lane selects.  A wave
+// issues about one instruction per 4-8 clk whatever it is, so a position costs what its instruction
+// count says (74 per position before this, profiles/r1k_scan_instruction_mix.txt).
+template <int GD, int DPL, bool FULL = false>
 GA_DEV void fwd_step(const float (&xs)[DPL], const float (&w)[5], float (&A)[DPL], float &m,
                      bool first, const LaneCtx &c, int D)
 {
   float An[DPL];
+  float mm;
   if (first) {
 #pragma unroll
     for (int i = 0; i < DPL; i++) {
@@ -88,12 +108,13 @@ GA_DEV void fwd_step(const float (&xs)[DPL], const float (&w)[5], float (&A)[DPL
     }
   } else {
     const float lo = seg_from_prev<GD>(xs[0], A[DPL - 1], c.lg);      // A[p-1][d0-1] | x
-    const float hi = seg_from_next<GD>(xs[DPL - 1], A[0], c.lg);      // A[p-1][d0+DPL] | x
+    float hi = seg_from_next<GD>(xs[DPL - 1], A[0], c.lg);            // A[p-1][d0+DPL] | x
+    if (FULL) hi = c.d0 + DPL == D ? xs[DPL - 1] : hi;                // the lane that owns d = D-1
 #pragma unroll
     for (int i = 0; i < DPL; i++) {
       const float P2 = i > 0 ? A[i - 1] : lo;
       float P3 = i < DPL - 1 ? A[i + 1] : hi;
-      if (c.d0 + i + 1 >= D) P3 = xs[i];
+      if (!FULL && c.d0 + i + 1 >= D) P3 = xs[i];
       float t = fmaf(xs[i], w[0], 0.0f);
       t = fmaf(A[i], w[1], t);
       t = fmaf(P2, w[2], t);
@@ -101,12 +122,22 @@ GA_DEV void fwd_step(const float (&xs)[DPL], const float (&w)[5], float (&A)[DPL
       An[i] = fmaf(m, w[4], t);
     }
   }
-  float mm = -INFINITY;
+  // (max taken straight on the FMA results: hipcc knows those are not signalling NaNs and emits bare
+  // v_max_f32 / v_max3_f32.  Lanes outside [0, D) are capped with fminf, not a select: behind a select
+  // every operand of the cross-lane reduction gets a quieting v_max_f32 x, x of its own, 8 per position)
+  if (FULL) {
+    mm = An[0];
 #pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    A[i] = An[i];
-    if (c.d0 + i < D) mm = fmaxf(mm, An[i]);
+    for (int i = 1; i < DPL; i++) mm = fmaxf(mm, An[i]);
+    mm = fminf(mm, c.cap);
+  } else {
+    mm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < DPL; i++)
+      if (c.d0 + i < D) mm = fmaxf(mm, An[i]);
   }
+#pragma unroll
+  for (int i = 0; i < DPL; i++) A[i] = An[i];
   m = seg_allmax<GD>(mm);
 }
 

@@ -28,6 +28,10 @@
 
 namespace ga {
 
+#ifndef SGA_ABLATE
+#define SGA_ABLATE 0     // development only: bit 0 no tile loads after the first batch, bit 1 no result stores
+#endif
+
 struct RowGeom {
   int D, H, W;
   int total_rows;   // S * H
@@ -40,50 +44,11 @@ template <int SBH, int PAD> struct RowCfg {
   static constexpr int PPI = 64 / PP;   // plane segments covered by one wave-wide access
 };
 
-// `lane` here is the lane within the 16-lane row (0..15)
-template <int DPL>
-GA_DEV void fwd_row_step(const float (&xs)[DPL], const float (&w)[5], float (&A)[DPL], float &m,
-                         bool first, int lane, int d0, int D)
-{
-  float An[DPL];
-  if (first) {
-#pragma unroll
-    for (int i = 0; i < DPL; i++) {
-      float t = fmaf(xs[i], w[0], 0.0f);
-      t = fmaf(xs[i], w[1], t);
-      t = fmaf(xs[i], w[2], t);
-      t = fmaf(xs[i], w[3], t);
-      An[i] = fmaf(xs[i], w[4], t);
-    }
-  } else {
-    const float lo = seg_from_prev<16>(xs[0], A[DPL - 1], lane);
-    const float hi = seg_from_next<16>(xs[DPL - 1], A[0], lane);
-#pragma unroll
-    for (int i = 0; i < DPL; i++) {
-      const float P2 = i > 0 ? A[i - 1] : lo;
-      float P3 = i < DPL - 1 ? A[i + 1] : hi;
-      if (d0 + i + 1 >= D) P3 = xs[i];
-      float t = fmaf(xs[i], w[0], 0.0f);
-      t = fmaf(A[i], w[1], t);
-      t = fmaf(P2, w[2], t);
-      t = fmaf(P3, w[3], t);
-      An[i] = fmaf(m, w[4], t);
-    }
-  }
-  float mm = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < DPL; i++) {
-    A[i] = An[i];
-    if (d0 + i < D) mm = fmaxf(mm, An[i]);
-  }
-  m = seg_allmax<16>(mm);
-}
-
 // grid.x = ceil(S*H / LN), block = 64: DPP row r of the wave owns image row blockIdx.x*LN + r
 // (rows >= LN mirror row r % LN).  desc: visit w = W-1 .. 0 (direction `left`).
 // dynamic LDS: LN * (D*RS + 5*SBH) floats (the A tile aliases the x tile).
-template <int DPL, int SBH, int PAD, int LN, bool desc>
-__global__ void __launch_bounds__(64)
+template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL>
+__global__ void __launch_bounds__(64, (DPL <= 5 ? 3 : 1))   // (<= 168 VGPRs incl. the prefetched tile where that fits)
 sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ A,
             RowGeom geo)
 {
@@ -100,6 +65,8 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   const int r = (lane >> 4) % LN;
   const bool owner = (lane >> 4) < LN;    // this lane's DPP row carries row r (not a mirror)
   const int d0 = rl * DPL;
+  LaneCtx c;
+  c.lg = rl; c.d0 = d0; c.line_ok = true; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   const int piece = lane % C::PP, psub = lane / C::PP;
   i64 vb[LN], gbo[LN];
   bool rok[LN];
@@ -118,24 +85,57 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   for (int i = 0; i < DPL; i++) Ap[i] = 0.f;
   float *xr = xt + r * D * C::RS, *ar = at + r * D * C::RS, *wr = wt + r * 5 * SBH;
 
-  for (int b = 0; b < nb; b++) {
-    const int w_lo = desc ? W - (b + 1) * SBH : b * SBH;
-    const int wq = w_lo + 4 * piece;
+  // Software pipeline: the next batch's tile is requested (into registers) BEFORE the current
+  // batch is computed and committed to LDS after it, so one HBM round trip overlaps 32 positions
+  // of recurrence instead of preceding them (written the obvious way -- load, ds_write, next piece
+  // -- hipcc emits load / s_waitcnt vmcnt(0) / ds_write per piece: nine serial round trips per
+  // batch, profiles/r1k_scan_instruction_mix.txt).  Loads are unconditional (addresses clamped
+  // into the row, the clamped copies are never committed): a conditional load makes the compiler
+  // guard every later use of its registers with vmcnt(0).
+  constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;      // pieces per lane and image row
+  float xpre[LN][NPC][4], wpre[LN][4];       // (plain floats: an f4 array carried around the loop stays in scratch)
+  auto batch_col = [&](int b) { return (desc ? W - (b + 1) * SBH : b * SBH) + 4 * piece; };
+  auto prefetch = [&](int b) {
+    int wq = batch_col(b < nb ? b : nb - 1);
+    wq = wq < 0 ? 0 : (wq > W - 4 ? W - 4 : wq);
+#pragma unroll
+    for (int q = 0; q < LN; q++) {
+      const float *xb = x + vb[q] + wq;
+#pragma unroll
+      for (int n = 0; n < NPC; n++) {
+        int pl = n * C::PPI + psub;
+        pl = pl < D ? pl : D - 1;
+        const f4 t = *reinterpret_cast<const f4 *>(xb + (i64)pl * geo.HW);
+        xpre[q][n][0] = t.x; xpre[q][n][1] = t.y; xpre[q][n][2] = t.z; xpre[q][n][3] = t.w;
+      }
+      const f4 t = *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)(psub < 5 ? psub : 4) * geo.HW + wq);
+      wpre[q][0] = t.x; wpre[q][1] = t.y; wpre[q][2] = t.z; wpre[q][3] = t.w;
+    }
+  };
+  auto commit = [&](int b) {
+    const int wq = batch_col(b);
     const bool col_ok = wq >= 0 && wq < W;
 #pragma unroll
     for (int q = 0; q < LN; q++) {
-      const float *xb = x + vb[q];
-      for (int p0 = 0; p0 < D; p0 += C::PPI) {
-        const int pl = p0 + psub;
+#pragma unroll
+      for (int n = 0; n < NPC; n++) {
+        const int pl = n * C::PPI + psub;
         if (pl < D && col_ok)
           *reinterpret_cast<f4 *>(xt + (q * D + pl) * C::RS + 4 * piece) =
-              *reinterpret_cast<const f4 *>(xb + (i64)pl * geo.HW + wq);
+              f4{xpre[q][n][0], xpre[q][n][1], xpre[q][n][2], xpre[q][n][3]};
       }
       if (psub < 5 && col_ok)
-        *reinterpret_cast<f4 *>(wt + (q * 5 + psub) * SBH + 4 * piece) =
-            *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)psub * geo.HW + wq);
+        *reinterpret_cast<f4 *>(wt + (q * 5 + psub) * SBH + 4 * piece) = f4{wpre[q][0], wpre[q][1], wpre[q][2], wpre[q][3]};
     }
-    __syncthreads();
+  };
+
+  prefetch(0);
+  for (int b = 0; b < nb; b++) {
+    const int wq = batch_col(b);
+    const bool col_ok = wq >= 0 && wq < W;
+    commit(b);
+    GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
+    prefetch(b + 1);
 #pragma unroll
     for (int kq = 0; kq < C::PP; kq++) {
       if (b * SBH + 4 * kq < W) {
@@ -156,7 +156,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
           for (int i = 0; i < DPL; i++) xs[i] = f4_get(xv[i], kk);
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
-          fwd_row_step<DPL>(xs, w, Ap, m, b == 0 && kq == 0 && k == 0, rl, d0, D);
+          fwd_step<16, DPL, FULL>(xs, w, Ap, m, b == 0 && kq == 0 && k == 0, c, D);
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Ap[i]);
         }
@@ -165,18 +165,19 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
           if (owner && d0 + i < D) *reinterpret_cast<f4 *>(ar + (d0 + i) * C::RS + 4 * cq) = ov[i];
       }
     }
-    __syncthreads();
+    GA_WAVE_SYNC();
 #pragma unroll
     for (int q = 0; q < LN; q++) {
       float *Ab = A + vb[q];
-      for (int p0 = 0; p0 < D; p0 += C::PPI) {
-        const int pl = p0 + psub;
+#pragma unroll
+      for (int n = 0; n < NPC; n++) {
+        const int pl = n * C::PPI + psub;
         if (pl < D && col_ok && rok[q])
           *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) =
               *reinterpret_cast<const f4 *>(at + (q * D + pl) * C::RS + 4 * piece);
       }
     }
-    __syncthreads();
+    GA_WAVE_SYNC();
   }
 }
 
@@ -207,7 +208,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   const int r = (lane >> 4) % LN;
   const bool owner = (lane >> 4) < LN;
   LaneCtx c;
-  c.lg = rl; c.d0 = rl * DPL; c.line_ok = true; c.s = 0; c.q = 0;
+  c.lg = rl; c.d0 = rl * DPL; c.line_ok = true; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   const int piece = lane % C::PP, psub = lane / C::PP;
   i64 vb[LN], gbo[LN], kbo[LN];
   bool rok[LN];
@@ -254,7 +255,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
         kt[q * (SBH / 2) + 2 * piece + 1] = kk2.y;
       }
     }
-    __syncthreads();
+    GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
 #pragma unroll
     for (int kq = 0; kq < C::PP; kq++) {
       if (b * SBH + 4 * kq < W) {
@@ -292,7 +293,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
           if (owner && c.d0 + i < D) *reinterpret_cast<f4 *>(gr + (c.d0 + i) * C::RS + 4 * cq) = ov[i];
       }
     }
-    __syncthreads();
+    GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
 #pragma unroll
     for (int q = 0; q < LN; q++) {
       for (int p0 = 0; p0 < D; p0 += C::PPI) {
@@ -302,7 +303,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
               *reinterpret_cast<const f4 *>(gt + q * TS + pl * C::RS + 4 * piece);
       }
     }
-    __syncthreads();
+    GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
   }
 }
 

@@ -42,6 +42,32 @@ def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
     assert max(err.values()) < 2e-5, err
 
 
+@pytest.mark.parametrize("wave,segs", [(0, 0), (1, 1), (1, 2), (1, 3), (1, 5), (1, 64), (2, 1), (2, 2), (2, 3), (2, 64)])
+@pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 5, 2, 36), 3),
+                                     ((1, 1, 3, 32), 2), ((1, 9, 1, 2), 2), ((1, 31, 3, 8), 2), ((1, 14, 2, 4), 1)])
+def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave, segs):
+    """256-thread tile kernels (0) vs the wave-autonomous kernels with register staging (1) and with the
+    LDS-DMA plane ring (2; widths that are not a multiple of 4 fall back to 1), the latter two with the
+    disparity range cut into 1..D segments (every seam, single-plane segments, more segments than
+    planes) and more planes than ring slots."""
+    rng = np.random.default_rng(sum(shape) + r)
+    fs = list(shape)
+    fs[1] = 3 * (2 * r + 1) ** 2
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal(fs), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y = port_oracle.lga_forward(x, f, r)
+    gx, gf = port_oracle.lga_backward(x, f, gy, r)
+    sim.set_option("GANET_LGA_WAVE", wave)
+    sim.set_option("GANET_LGA_SEGS", segs)
+    try:
+        err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_SEGS", 0)
+
+
 def test_cost_volume_and_regression(sim, port_oracle):
     rng = np.random.default_rng(5)
     N, C, H, W, maxdisp = 2, 3, 4, 11, 6
