@@ -1,0 +1,50 @@
+// ga_launch.h -- what the translation units of libganet_hip.so share on the host side: the launch
+// macros (HIP / CPU emulator), the row-kernel tiling constants and the launchers that live in their
+// own translation unit.
+#pragma once
+#include "ga_common.h"
+#include "sga_row_kernels.h"
+
+#if defined(GA_HIPSIM)
+#define GA_LAUNCH(kern, grid, block, stream, ...) \
+  hipsim::launch((grid), (block), 0, [=]() { kern(__VA_ARGS__); })
+#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
+  hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define GA_EXPORT extern "C"
+#else
+// hipGetLastError() is per-thread state shared with the host framework: drop whatever an earlier,
+// unrelated HIP call left there so check_launch() reports THIS launch
+#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
+  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
+#define GA_LAUNCH(kern, grid, block, stream, ...) \
+  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
+#define GA_EXPORT extern "C" __attribute__((visibility("default")))
+#endif
+
+namespace ga {
+
+// rows per wavefront (LN) x positions per staged batch (SBH): LDS per wave bounds residency
+constexpr int ROW_SBH_F = 32, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: the A tile overwrites the x tile (9.8 KB per row at D=65)
+constexpr size_t ROW_SMEM_MAX = 64 * 1024;
+
+inline size_t row_smem_fwd(int D)
+{
+  return sizeof(float) * ROW_LN_F * ((size_t)D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
+}
+
+// disparities per lane of the single DPP row that carries the recurrence (D <= 16 * DPL)
+#define GA_ROW_DPLS(X) X(1) X(2) X(3) X(5) X(9) X(13)
+
+inline int row_dpl(int D)
+{
+  int best = 0;
+#define X(P) if (best == 0 && 16 * (P) >= D) best = (P);
+  GA_ROW_DPLS(X)
+#undef X
+  return best;
+}
+
+// sga_row_fwd_tu.hip: horizontal forward scans (direction 2 = right, 3 = left); the caller checks the launch
+void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st);
+
+}  // namespace ga

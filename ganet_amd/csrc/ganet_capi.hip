@@ -17,21 +17,7 @@
 
 #include "../../include/ganet_hip.h"
 
-#if defined(GA_HIPSIM)
-#define GA_LAUNCH(kern, grid, block, stream, ...) \
-  hipsim::launch((grid), (block), 0, [=]() { kern(__VA_ARGS__); })
-#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
-  hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
-#define GA_EXPORT extern "C"
-#else
-// hipGetLastError() is per-thread state shared with the host framework: drop whatever an earlier,
-// unrelated HIP call left there so check_launch() reports THIS launch
-#define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
-  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
-#define GA_LAUNCH(kern, grid, block, stream, ...) \
-  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
-#define GA_EXPORT extern "C" __attribute__((visibility("default")))
-#endif
+#include "ga_launch.h"
 
 namespace {
 
@@ -251,14 +237,6 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
 }
 
 // ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
-// rows per wavefront (LN) x positions per staged batch (SBH): LDS per wave bounds residency
-constexpr int ROW_SBH_F = 32, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: 2 tiles per row  (10.7 KB per row at D=65)
-constexpr size_t ROW_SMEM_MAX = 64 * 1024;
-
-size_t row_smem_fwd(int D)
-{
-  return sizeof(float) * ROW_LN_F * ((size_t)D * RowCfg<ROW_SBH_F, ROW_PAD_F>::RS + 5 * ROW_SBH_F);
-}
 constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
 size_t row_smem_bwdg(int D)
 {
@@ -272,35 +250,9 @@ bool rowwave_ok(int D, int W, int dir, size_t smem)
   return opts().rowwave && dir >= 2 && W % 4 == 0 && D <= 16 * 13 && smem <= ROW_SMEM_MAX;
 }
 
-// disparities per lane of the single DPP row that carries the recurrence (D <= 16 * DPL)
-#define GA_ROW_DPLS(X) X(1) X(2) X(3) X(5) X(9) X(13)
-
-int row_dpl(int D)
-{
-  int best = 0;
-#define X(P) if (best == 0 && 16 * (P) >= D) best = (P);
-  GA_ROW_DPLS(X)
-#undef X
-  return best;
-}
-
 int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
 {
-  RowGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
-  const int dpl = row_dpl(D);
-  const bool full = dpl > 0 && D % dpl == 0;     // lanes wholly inside / outside [0, D): leaner recurrence
-  const size_t smem = row_smem_fwd(D);
-  const dim3 grid((S * H + ROW_LN_F - 1) / ROW_LN_F), block(64);
-#define X(P)                                                                                        \
-  if (dpl == (P)) {                                                                                 \
-    if (dir == 3 && full) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true, true>), grid, block, smem, st, x, g, A, geo);  \
-    else if (dir == 3) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true, false>), grid, block, smem, st, x, g, A, geo);  \
-    else if (full) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false, true>), grid, block, smem, st, x, g, A, geo);      \
-    else GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, false, false>), grid, block, smem, st, x, g, A, geo);               \
-  }
-  GA_ROW_DPLS(X)
-#undef X
+  launch_row_fwd(x, g, A, S, D, H, W, dir, st);      // sga_row_fwd_tu.hip (own translation unit, own flags)
   return check_launch("sga row forward");
 }
 

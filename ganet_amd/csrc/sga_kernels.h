@@ -622,7 +622,7 @@ sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const f
 }
 
 // first-argmax over d of one directional volume (reference-compatible path; MaxDepth :50-64)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 sga_argmax_px(const float *__restrict__ A, uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
 {
   const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -655,7 +655,7 @@ sga_merge_running(const float *__restrict__ tmp, float *__restrict__ out, MaskT 
 }
 
 // float-valued mask (reference layout) -> uint8
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 mask_f32_to_u8(const float *__restrict__ m, uint8_t *__restrict__ o, i64 n)
 {
   const i64 stride = (i64)gridDim.x * blockDim.x;

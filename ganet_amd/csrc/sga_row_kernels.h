@@ -187,7 +187,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 // dynamic LDS per image row: D*RS (gradOut -> G) + roundup4(D*(PP+1)) mask words + 5*SBH (w)
 // + SBH/2 words (kp as uint16).
 template <int DPL, int SBH, int PAD, int LN, bool desc>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (DPL <= 5 ? 3 : 1))
 sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
              const uint16_t *__restrict__ kp, const float *__restrict__ gout,
              float *__restrict__ G, RowGeom geo, int dir)
@@ -232,30 +232,62 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   const uint32_t *mr = mt + r * MW, *kr = kt + r * (SBH / 2);
   const float *wr = wt + r * 5 * SBH;
 
-  for (int b = 0; b < nb; b++) {
-    const int w_lo = desc ? W - (b + 1) * SBH : b * SBH;
-    const int wq = w_lo + 4 * piece;
+  // software pipeline as in sga_row_fwd: the next batch's gradOut / mask / guidance / arg-max pieces
+  // are requested before the current batch is computed and committed to LDS after it
+  constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;
+  float gpre[LN][NPC][4], wpre[LN][4];
+  uint32_t mpre[LN][NPC], kpre[LN][2];
+  auto batch_col = [&](int b) { return (desc ? W - (b + 1) * SBH : b * SBH) + 4 * piece; };
+  auto prefetch = [&](int b) {
+    int wq = batch_col(b < nb ? b : nb - 1);
+    wq = wq < 0 ? 0 : (wq > W - 4 ? W - 4 : wq);
+#pragma unroll
+    for (int q = 0; q < LN; q++) {
+#pragma unroll
+      for (int n = 0; n < NPC; n++) {
+        int pl = n * C::PPI + psub;
+        pl = pl < D ? pl : D - 1;
+        const i64 o = vb[q] + (i64)pl * geo.HW + wq;
+        const f4 t = *reinterpret_cast<const f4 *>(gout + o);
+        gpre[q][n][0] = t.x; gpre[q][n][1] = t.y; gpre[q][n][2] = t.z; gpre[q][n][3] = t.w;
+        mpre[q][n] = *reinterpret_cast<const uint32_t *>(mask + o);
+      }
+      const f4 t = *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)(psub < 5 ? psub : 4) * geo.HW + wq);
+      wpre[q][0] = t.x; wpre[q][1] = t.y; wpre[q][2] = t.z; wpre[q][3] = t.w;
+      const uint2 kk2 = *reinterpret_cast<const uint2 *>(kp + kbo[q] + wq);   // 4 x uint16
+      kpre[q][0] = kk2.x; kpre[q][1] = kk2.y;
+    }
+  };
+  auto commit = [&](int b) {
+    const int wq = batch_col(b);
     const bool col_ok = wq >= 0 && wq < W;
 #pragma unroll
     for (int q = 0; q < LN; q++) {
-      for (int p0 = 0; p0 < D; p0 += C::PPI) {
-        const int pl = p0 + psub;
+#pragma unroll
+      for (int n = 0; n < NPC; n++) {
+        const int pl = n * C::PPI + psub;
         if (pl < D && col_ok) {
-          const i64 o = vb[q] + (i64)pl * geo.HW + wq;
-          *reinterpret_cast<f4 *>(gt + q * TS + pl * C::RS + 4 * piece) = *reinterpret_cast<const f4 *>(gout + o);
-          mt[q * MW + pl * MS + piece] = *reinterpret_cast<const uint32_t *>(mask + o);
+          *reinterpret_cast<f4 *>(gt + q * TS + pl * C::RS + 4 * piece) =
+              f4{gpre[q][n][0], gpre[q][n][1], gpre[q][n][2], gpre[q][n][3]};
+          mt[q * MW + pl * MS + piece] = mpre[q][n];
         }
       }
       if (psub < 5 && col_ok)
-        *reinterpret_cast<f4 *>(wt + (q * 5 + psub) * SBH + 4 * piece) =
-            *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)psub * geo.HW + wq);
+        *reinterpret_cast<f4 *>(wt + (q * 5 + psub) * SBH + 4 * piece) = f4{wpre[q][0], wpre[q][1], wpre[q][2], wpre[q][3]};
       if (psub == 5 && col_ok) {
-        const uint2 kk2 = *reinterpret_cast<const uint2 *>(kp + kbo[q] + wq);   // 4 x uint16
-        kt[q * (SBH / 2) + 2 * piece] = kk2.x;
-        kt[q * (SBH / 2) + 2 * piece + 1] = kk2.y;
+        kt[q * (SBH / 2) + 2 * piece] = kpre[q][0];
+        kt[q * (SBH / 2) + 2 * piece + 1] = kpre[q][1];
       }
     }
+  };
+
+  prefetch(0);
+  for (int b = 0; b < nb; b++) {
+    const int wq = batch_col(b);
+    const bool col_ok = wq >= 0 && wq < W;
+    commit(b);
     GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
+    prefetch(b + 1);
 #pragma unroll
     for (int kq = 0; kq < C::PP; kq++) {
       if (b * SBH + 4 * kq < W) {
