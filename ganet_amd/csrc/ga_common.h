@@ -92,6 +92,16 @@ GA_DEV int lane_id()
 #endif
 }
 
+// Workgroup barrier for hand-offs that go through LDS only.  __syncthreads() is a fence + barrier, and
+// the fence drains the vector-memory counter as well: every global load still in flight (the prefetch
+// of the next tile) and every result store is waited for at each barrier.  Here only the LDS queue
+// is drained (cdna_hip_programming.md, "raw s_barrier + lgkmcnt(0) only").
+#if defined(GA_HIPSIM)
+#define GA_LDS_BARRIER() __syncthreads()
+#else
+#define GA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // hand-off between the lanes of ONE wavefront through LDS (kernels whose workgroup is a single wave)
 #if defined(GA_HIPSIM)
 #define GA_WAVE_SYNC() __syncthreads()     // emulator: the block IS one wave in these kernels

@@ -260,7 +260,7 @@ int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
 size_t col_smem_fwd(int D) { return sizeof(float) * ((size_t)2 * COL_NC * D * COL_SBV + COL_NC * 5 * COL_SBV); }
 size_t col_smem_bwdg(int D)
 {
-  return sizeof(float) * ((size_t)COL_NC * D * COL_SBV + COL_NC * 5 * COL_SBV + COL_NC * COL_SBV) +
+  return sizeof(float) * ((size_t)2 * COL_NC * D * COL_SBV + COL_NC * 5 * COL_SBV + COL_NC * COL_SBV) +
          (size_t)D * COL_SBV * 16;
 }
 bool colblock_ok(int D, int W, int dir, size_t smem)

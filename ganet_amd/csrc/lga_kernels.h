@@ -218,7 +218,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
   float regs[C::NLD];
   lga_stage_fetch<R>(xb, geo, stg, 0, regs);
   lga_stage_commit<R>(tile[0], regs);
-  __syncthreads();
+  GA_LDS_BARRIER();
 
   float acc_a = 0.f, acc_b = 0.f;   // partial y[d-1], y[d] while visiting plane d
   float xc_prev = 0.f;
@@ -291,7 +291,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
       }
     }
     if (more) lga_stage_commit<R>(tile[(c + 1) & 1], regs);
-    __syncthreads();
+    GA_LDS_BARRIER();
   }
   {
     const int dy = geo.D - 1;
@@ -826,7 +826,7 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
   float regs[C::NLD];
   lga_stage_fetch<R>(xb, geo, stg, 0, regs);
   lga_stage_commit<R>(tile[0], regs);
-  __syncthreads();
+  GA_LDS_BARRIER();
 
   // gy of the own pixel at planes d-1, d, d+1 (rolling); the next chunk's values are fetched
   // one chunk ahead so the march never waits on a dependent global load
@@ -881,7 +881,7 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
       }
     }
     if (more) lga_stage_commit<R>(tile[(c + 1) & 1], regs);
-    __syncthreads();
+    GA_LDS_BARRIER();
   }
 
   if (inb) {

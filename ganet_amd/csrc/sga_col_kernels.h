@@ -107,11 +107,15 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   for (int it = 0; it < NIT; it++) { st[it].x = 0.f; st[it].y = 0.f; st[it].z = 0.f; st[it].w = 0.f; }
   sw.x = 0.f; sw.y = 0.f; sw.z = 0.f; sw.w = 0.f;
 
+  // Order inside a batch: compute -> barrier -> commit the NEXT batch's x tile (prefetched into
+  // registers before the compute) -> store this batch's A tile -> barrier -> prefetch.  The commit
+  // waits on the vector-memory counter, which also counts stores: placed right behind the result
+  // stores (as it first was) it waited for THEIR completion, one HBM write round trip per 4 rows.
   GA_COL_FETCH(0)
+  GA_COL_COMMIT()
+  GA_LDS_BARRIER();
+  if (1 < nb) { GA_COL_FETCH(1) }
   for (int b = 0; b < nb; b++) {
-    GA_COL_COMMIT()
-    __syncthreads();
-    if (b + 1 < nb) { GA_COL_FETCH(b + 1) }
     // compute: 4 positions out of LDS
     {
       f4 xv[DPL], wv4[5], ov[DPL];
@@ -139,7 +143,8 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
       for (int i = 0; i < DPL; i++)
         if (c.d0 + i < D) *reinterpret_cast<f4 *>(at + (cidx * D + c.d0 + i) * SB) = ov[i];
     }
-    __syncthreads();
+    GA_LDS_BARRIER();
+    if (b + 1 < nb) { GA_COL_COMMIT() }
     // copy out the A tile of this batch
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
@@ -156,6 +161,8 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
         *reinterpret_cast<f4 *>(A + sbase + (i64)d * geo.HW + (i64)row * W + c0 + 4 * piece) = o;
       }
     }
+    GA_LDS_BARRIER();
+    if (b + 2 < nb) { GA_COL_FETCH(b + 2) }
   }
 #undef GA_COL_FETCH
 #undef GA_COL_COMMIT
@@ -163,7 +170,7 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 
 // ---- adjoint scan (backward step 1) over column blocks ---------------------------------------------
 // asc: VISIT order rows 0..H-1 (adjoint of `up`), else H-1..0 (adjoint of `down`).
-// dynamic LDS: 16*D*4 floats (gradOut -> G in place) + 16*5*4 floats (guidance)
+// dynamic LDS: 2 x 16*D*4 floats (gradOut -> G in place, double-buffered) + 16*5*4 floats (guidance)
 //              + D*4*16 bytes (mask) + 16*4 ints (kp).
 template <int DPL, bool asc>
 __global__ void __launch_bounds__(256)
@@ -176,8 +183,8 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   constexpr int NITM = (16 * DPL * SB + 255) / 256;      // mask: one 16-byte piece per (plane,row)
   GA_DYN_SMEM(smem);
   const int D = geo.D, H = geo.H, W = geo.W;
-  float *gt = smem;                                        // [NC][D][SB]
-  float *wt = gt + NC * D * SB;                            // [NC][5][SB]
+  float *gt = smem;                                        // [2][NC][D][SB]
+  float *wt = gt + 2 * NC * D * SB;                        // [NC][5][SB]
   int *kt = reinterpret_cast<int *>(wt + NC * 5 * SB);     // [NC][SB]
   uint8_t *mt = reinterpret_cast<uint8_t *>(kt + NC * SB); // [D][SB][16]
   const int tid = threadIdx.x;
@@ -240,15 +247,15 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       sk = (int)kp[kbase + (i64)row * W + c0 + cc];                                \
     }                                                                              \
   }
-#define GA_COL_COMMIT()                                                            \
+#define GA_COL_COMMIT(GT)                                                          \
   _Pragma("unroll") for (int it = 0; it < NIT; it++) {                             \
     const int seg = it * 64 + seg0;                                                \
     const int d = seg / SB, j = seg - d * SB;                                      \
     if (seg < nseg) {                                                              \
-      gt[((4 * piece + 0) * D + d) * SB + j] = st[it].x;                           \
-      gt[((4 * piece + 1) * D + d) * SB + j] = st[it].y;                           \
-      gt[((4 * piece + 2) * D + d) * SB + j] = st[it].z;                           \
-      gt[((4 * piece + 3) * D + d) * SB + j] = st[it].w;                           \
+      (GT)[((4 * piece + 0) * D + d) * SB + j] = st[it].x;                           \
+      (GT)[((4 * piece + 1) * D + d) * SB + j] = st[it].y;                           \
+      (GT)[((4 * piece + 2) * D + d) * SB + j] = st[it].z;                           \
+      (GT)[((4 * piece + 3) * D + d) * SB + j] = st[it].w;                           \
     }                                                                              \
   }                                                                                \
   _Pragma("unroll") for (int it = 0; it < NITM; it++) {                            \
@@ -278,17 +285,24 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   for (int it = 0; it < NITM; it++) { sm[it].x = 0u; sm[it].y = 0u; sm[it].z = 0u; sm[it].w = 0u; }
   sw.x = 0.f; sw.y = 0.f; sw.z = 0.f; sw.w = 0.f;
 
+  // Batch order as in sga_col_fwd: compute -> barrier -> commit the next batch (prefetched into
+  // registers before the compute) -> store this batch's G -> barrier -> prefetch.  G overwrites the
+  // gradOut tile in place, so that tile is double-buffered: the next batch can be committed while
+  // this batch's result is still being copied out, and the commit's wait on the vector-memory
+  // counter never lands right behind the result stores.
+  const int TS = NC * D * SB;
   GA_COL_FETCH(0)
+  GA_COL_COMMIT(gt)
+  GA_LDS_BARRIER();
+  if (1 < nb) { GA_COL_FETCH(1) }
   for (int b = 0; b < nb; b++) {
-    GA_COL_COMMIT()
-    __syncthreads();
-    if (b + 1 < nb) { GA_COL_FETCH(b + 1) }
+    float *gc = gt + (b & 1) * TS, *gnx = gt + ((b + 1) & 1) * TS;
     {
       f4 gov[DPL], wv4[5], ov[DPL];
 #pragma unroll
       for (int i = 0; i < DPL; i++) {
         const int d = c.d0 + i < D ? c.d0 + i : D - 1;
-        gov[i] = *reinterpret_cast<const f4 *>(gt + (cidx * D + d) * SB);
+        gov[i] = *reinterpret_cast<const f4 *>(gc + (cidx * D + d) * SB);
       }
 #pragma unroll
       for (int t = 0; t < 5; t++) wv4[t] = *reinterpret_cast<const f4 *>(wt + (cidx * 5 + t) * SB);
@@ -315,9 +329,10 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       }
 #pragma unroll
       for (int i = 0; i < DPL; i++)
-        if (c.d0 + i < D) *reinterpret_cast<f4 *>(gt + (cidx * D + c.d0 + i) * SB) = ov[i];
+        if (c.d0 + i < D) *reinterpret_cast<f4 *>(gc + (cidx * D + c.d0 + i) * SB) = ov[i];
     }
-    __syncthreads();
+    GA_LDS_BARRIER();
+    if (b + 1 < nb) { GA_COL_COMMIT(gnx) }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int seg = it * 64 + seg0;
@@ -326,14 +341,15 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       if (seg < nseg && p < H && pcol_ok) {
         const int row = asc ? p : H - 1 - p;
         f4 o;
-        o.x = gt[((4 * piece + 0) * D + d) * SB + j];
-        o.y = gt[((4 * piece + 1) * D + d) * SB + j];
-        o.z = gt[((4 * piece + 2) * D + d) * SB + j];
-        o.w = gt[((4 * piece + 3) * D + d) * SB + j];
+        o.x = gc[((4 * piece + 0) * D + d) * SB + j];
+        o.y = gc[((4 * piece + 1) * D + d) * SB + j];
+        o.z = gc[((4 * piece + 2) * D + d) * SB + j];
+        o.w = gc[((4 * piece + 3) * D + d) * SB + j];
         *reinterpret_cast<f4 *>(G + sbase + (i64)d * geo.HW + (i64)row * W + c0 + 4 * piece) = o;
       }
     }
-    __syncthreads();   // the G tile is also the next batch's input tile
+    GA_LDS_BARRIER();
+    if (b + 2 < nb) { GA_COL_FETCH(b + 2) }
   }
 #undef GA_COL_FETCH
 #undef GA_COL_COMMIT
