@@ -72,10 +72,15 @@ struct LgaGeom {
 
 // Cooperative stage load: planes [d0, d0+PB) of the tile (+halo) -> registers -> LDS.
 // Which tile cell a thread copies does not depend on the chunk, so the (plane-in-chunk,
-// element offset, in-image) triple is computed ONCE per kernel.
+// element offset, in-image) triple is computed ONCE per kernel.  The loads themselves are
+// unconditional: an always-valid address, the value ANDed with an all-ones / zero mask.  Written as
+// "inside ? load : 0", every load sits in a branch of its own and hipcc, unable to tell whether one
+// is still pending, guards the next use of the staging registers with s_waitcnt vmcnt(0) -- right
+// behind the prefetch it was meant to overlap (profiles/r1k_scan_instruction_mix.txt).
 template <int R> struct LgaStage {
-  int off[LgaCfg<R>::NLD];     // element offset from the chunk's first plane, or -1 = write zero
-  int pl[LgaCfg<R>::NLD];      // plane within the chunk
+  int off[LgaCfg<R>::NLD];          // element offset from the chunk's first plane (0 if outside the image)
+  unsigned msk[LgaCfg<R>::NLD];     // ~0u inside the image, 0 outside
+  int pl[LgaCfg<R>::NLD];           // plane within the chunk
 };
 template <int R>
 GA_DEV void lga_stage_init(LgaStage<R> &st, const LgaGeom &geo, int ty0, int tx0)
@@ -84,35 +89,40 @@ GA_DEV void lga_stage_init(LgaStage<R> &st, const LgaGeom &geo, int ty0, int tx0
 #pragma unroll
   for (int l = 0; l < C::NLD; l++) {
     const int e = l * 256 + (int)threadIdx.x;
-    st.off[l] = -1;
+    st.off[l] = 0;
+    st.msk[l] = 0u;
     st.pl[l] = 0;
     if (e < C::STAGE) {
       const int pl = e / C::PLANE, rem = e - pl * C::PLANE;
       const int r = rem / C::TW2, cc = rem - r * C::TW2;
       const int i = ty0 + r - R, j = tx0 + cc - C::RE;
       st.pl[l] = pl;
-      if (i >= 0 && i < geo.H && j >= 0 && j < geo.W) st.off[l] = (int)(pl * geo.HW + (i64)i * geo.W + j);
+      if (i >= 0 && i < geo.H && j >= 0 && j < geo.W) { st.off[l] = i * geo.W + j; st.msk[l] = ~0u; }
     }
   }
 }
 template <int R>
 GA_DEV void lga_stage_fetch(const float *__restrict__ xb, const LgaGeom &geo, const LgaStage<R> &st,
-                            int d0, float (&regs)[LgaCfg<R>::NLD])
+                            int d0, unsigned (&regs)[LgaCfg<R>::NLD])
 {
   typedef LgaCfg<R> C;
-  const float *base = xb + (i64)d0 * geo.HW;
 #pragma unroll
-  for (int l = 0; l < C::NLD; l++)
-    regs[l] = (st.off[l] >= 0 && d0 + st.pl[l] < geo.D) ? base[st.off[l]] : 0.f;
+  for (int l = 0; l < C::NLD; l++) {
+    int d = d0 + st.pl[l];
+    d = d < geo.D ? d : geo.D - 1;                      // (past the last plane: a copy that is masked below)
+    regs[l] = *reinterpret_cast<const unsigned *>(xb + (i64)d * geo.HW + st.off[l]);
+  }
 }
 template <int R>
-GA_DEV void lga_stage_commit(float *__restrict__ buf, const float (&regs)[LgaCfg<R>::NLD])
+GA_DEV void lga_stage_commit(float *__restrict__ buf, const LgaGeom &geo, const LgaStage<R> &st, int d0,
+                             const unsigned (&regs)[LgaCfg<R>::NLD])
 {
   typedef LgaCfg<R> C;
 #pragma unroll
   for (int l = 0; l < C::NLD; l++) {
     const int e = l * 256 + (int)threadIdx.x;
-    if (e < C::STAGE) buf[e] = regs[l];
+    const unsigned m = d0 + st.pl[l] < geo.D ? st.msk[l] : 0u;
+    if (e < C::STAGE) reinterpret_cast<unsigned *>(buf)[e] = regs[l] & m;
   }
 }
 
@@ -215,17 +225,16 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
   const int nchunks = (geo.D + LGA_PB - 1) / LGA_PB;
   LgaStage<R> stg;
   lga_stage_init<R>(stg, geo, ty0, tx0);
-  float regs[C::NLD];
+  unsigned regs[C::NLD];
   lga_stage_fetch<R>(xb, geo, stg, 0, regs);
-  lga_stage_commit<R>(tile[0], regs);
+  lga_stage_commit<R>(tile[0], geo, stg, 0, regs);
   GA_LDS_BARRIER();
 
   float acc_a = 0.f, acc_b = 0.f;   // partial y[d-1], y[d] while visiting plane d
   float xc_prev = 0.f;
   float *yp = yb + pix;               // output cursor: plane d-1 of the own pixel
   for (int c = 0; c < nchunks; c++) {
-    const bool more = c + 1 < nchunks;
-    if (more) lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);
+    lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);       // (unconditional: past the end it is a masked copy)
     const lds_cptr buf = GA_LDS_CPTR(&tile[0][0]) + (c & 1) * C::STAGE;
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
@@ -290,7 +299,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
         xc_prev = xc;
       }
     }
-    if (more) lga_stage_commit<R>(tile[(c + 1) & 1], regs);
+    lga_stage_commit<R>(tile[(c + 1) & 1], geo, stg, (c + 1) * LGA_PB, regs);
     GA_LDS_BARRIER();
   }
   {
@@ -823,26 +832,29 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
   const int nchunks = (geo.D + LGA_PB - 1) / LGA_PB;
   LgaStage<R> stg;
   lga_stage_init<R>(stg, geo, ty0, tx0);
-  float regs[C::NLD];
+  unsigned regs[C::NLD];
   lga_stage_fetch<R>(xb, geo, stg, 0, regs);
-  lga_stage_commit<R>(tile[0], regs);
+  lga_stage_commit<R>(tile[0], geo, stg, 0, regs);
   GA_LDS_BARRIER();
 
   // gy of the own pixel at planes d-1, d, d+1 (rolling); the next chunk's values are fetched
   // one chunk ahead so the march never waits on a dependent global load
   float g_m = 0.f, g_0 = gyb[pix];
-  float gnext[LGA_PB];
+  unsigned gnext[LGA_PB];
+  auto gy_fetch = [&](int dn) {          // gy[dn] of the own pixel, 0 past the last plane; unconditional load
+    const int dc = dn < geo.D ? dn : geo.D - 1;
+    const unsigned v = *reinterpret_cast<const unsigned *>(gyb + (i64)dc * geo.HW + pix);
+    return v & (dn < geo.D ? ~0u : 0u);
+  };
 #pragma unroll
-  for (int pl = 0; pl < LGA_PB; pl++) gnext[pl] = pl + 1 < geo.D ? gyb[(i64)(pl + 1) * geo.HW + pix] : 0.f;
+  for (int pl = 0; pl < LGA_PB; pl++) gnext[pl] = gy_fetch(pl + 1);
   for (int c = 0; c < nchunks; c++) {
-    const bool more = c + 1 < nchunks;
-    if (more) lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);
+    lga_stage_fetch<R>(xb, geo, stg, (c + 1) * LGA_PB, regs);       // (unconditional: past the end it is a masked copy)
     float gcur[LGA_PB];
 #pragma unroll
     for (int pl = 0; pl < LGA_PB; pl++) {
-      gcur[pl] = gnext[pl];
-      const int dn = (c + 1) * LGA_PB + pl + 1;
-      gnext[pl] = dn < geo.D ? gyb[(i64)dn * geo.HW + pix] : 0.f;
+      gcur[pl] = i2f((int)gnext[pl]);
+      gnext[pl] = gy_fetch((c + 1) * LGA_PB + pl + 1);
     }
     const lds_cptr buf = GA_LDS_CPTR(&tile[0][0]) + (c & 1) * C::STAGE;
 #pragma unroll
@@ -880,7 +892,7 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
         g_0 = g_p;
       }
     }
-    if (more) lga_stage_commit<R>(tile[(c + 1) & 1], regs);
+    lga_stage_commit<R>(tile[(c + 1) & 1], geo, stg, (c + 1) * LGA_PB, regs);
     GA_LDS_BARRIER();
   }
 
