@@ -66,6 +66,7 @@ struct Options {
   int lga_segs = 0;   // depth segments per tile for those kernels (0 = automatic)
   int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
   int colblock = 1;     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
+  int merge4 = 1;       // merge + arg-max: four pixels per lane (16-byte requests)
   int block_v = 128;
   int block_h = 64;
 };
@@ -85,6 +86,7 @@ void load_env_options()
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
+  geti("GANET_SGA_MERGE4", g_opt.merge4);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
   geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
@@ -518,7 +520,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
-
+  else if (!strcmp(name, "GANET_SGA_MERGE4")) g_opt.merge4 = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
@@ -560,8 +562,15 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   } else {
     for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   }
+  const i64 HWl = (i64)H * W;
+  if (opts().merge4 && HWl % 4 == 0 && aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) &&
+      (((uintptr_t)kp & 7) == 0) && npix / 4 / 64 + 1 < (1ll << 31)) {
+    GA_LAUNCH(sga_merge_px4, dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
+              A_ws + 3 * n, out, mask, kp, D, HWl, npix);
+    return check_launch("sga merge (4 px / lane)");
+  }
   GA_LAUNCH((sga_merge_px<uint8_t>), dim3(px_grid(npix)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
-            A_ws + 3 * n, out, mask, kp, D, (i64)H * W, npix);
+            A_ws + 3 * n, out, mask, kp, D, HWl, npix);
   return check_launch("sga merge");
 }
 

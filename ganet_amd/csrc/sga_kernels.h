@@ -621,6 +621,87 @@ sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const f
   }
 }
 
+// Same merge, FOUR consecutive pixels per lane: every access is a 16-byte load / store (the mask
+// leaves as one packed dword, kp as one 8-byte store), DU planes of loads in flight per lane.  The
+// one-pixel-per-lane form above issues 4-byte requests and tops out at ~4.4 TB/s; a streaming kernel
+// of 16-byte requests reaches ~6.3 TB/s on this chip (scripts/ubench/mall_probe.py).
+// Needs HW % 4 == 0 and 16-byte aligned volumes (launcher checks).
+#ifndef GA_MERGE_DU
+#define GA_MERGE_DU 1
+#endif
+static __global__ void __launch_bounds__(64)
+sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
+              const float *__restrict__ A3, float *__restrict__ out, uint8_t *__restrict__ mask,
+              uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
+{
+  constexpr int DU = GA_MERGE_DU;
+  const i64 nq = npix >> 2;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 qidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; qidx < nq; qidx += stride) {
+    const i64 pidx = qidx << 2;
+    const i64 s = pidx / HW, pix = pidx - s * HW;
+    const i64 vb = s * D * HW + pix;
+    float m[4][4];
+    int k[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { m[q][j] = 0.f; k[q][j] = 0; }
+    for (int dc = 0; dc < D; dc += DU) {
+      f4 a[DU][4];
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u < D ? dc + u : D - 1;
+        const i64 o = vb + (i64)d * HW;
+        a[u][0] = *reinterpret_cast<const f4 *>(A0 + o);
+        a[u][1] = *reinterpret_cast<const f4 *>(A1 + o);
+        a[u][2] = *reinterpret_cast<const f4 *>(A2 + o);
+        a[u][3] = *reinterpret_cast<const f4 *>(A3 + o);
+      }
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u;
+        if (d < D) {
+          float v[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) { v[q][0] = a[u][q].x; v[q][1] = a[u][q].y; v[q][2] = a[u][q].z; v[q][3] = a[u][q].w; }
+          float ov[4];
+          unsigned mk = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float o_ = v[0][j];
+            unsigned mj = 0;
+            if (o_ < v[1][j]) { o_ = v[1][j]; mj = 1; }
+            if (o_ < v[2][j]) { o_ = v[2][j]; mj = 2; }
+            if (o_ < v[3][j]) { o_ = v[3][j]; mj = 3; }
+            ov[j] = o_;
+            mk |= mj << (8 * j);
+          }
+          const i64 o = vb + (i64)d * HW;
+          f4 r;
+          r.x = ov[0]; r.y = ov[1]; r.z = ov[2]; r.w = ov[3];
+          *reinterpret_cast<f4 *>(out + o) = r;
+          *reinterpret_cast<unsigned *>(mask + o) = mk;
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (d == 0) m[q][j] = v[q][j];
+              else if (m[q][j] < v[q][j]) { m[q][j] = v[q][j]; k[q][j] = d; }
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint2 pk;
+      pk.x = (unsigned)k[q][0] | ((unsigned)k[q][1] << 16);
+      pk.y = (unsigned)k[q][2] | ((unsigned)k[q][3] << 16);
+      *reinterpret_cast<uint2 *>(kp + (i64)q * npix + pidx) = pk;
+    }
+  }
+}
+
 // first-argmax over d of one directional volume (reference-compatible path; MaxDepth :50-64)
 static __global__ void __launch_bounds__(256)
 sga_argmax_px(const float *__restrict__ A, uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
