@@ -32,6 +32,10 @@ namespace ga {
 #define SGA_ABLATE 0     // development only: bit 0 no tile loads after the first batch, bit 1 no result stores
 #endif
 
+#ifndef GA_ROW_ALIGN
+#define GA_ROW_ALIGN 1   // 0: batches counted from the row start (A/B only)
+#endif
+
 struct RowGeom {
   int D, H, W;
   int total_rows;   // S * H
@@ -79,7 +83,15 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
     vb[q] = (i64)s * D * geo.HW + (i64)h * W;
     gbo[q] = (i64)s * 5 * geo.HW + (i64)h * W;
   }
-  const int nb = (W + SBH - 1) / SBH;
+  // Line-aligned batches: a batch covers SBH elements that start on a multiple of SBH elements of the
+  // ADDRESS (one or two whole 128-byte lines per plane), not of the row.  Rows of W = 208 floats start
+  // 64 B into a line every other row; batches counted from the row start then straddle two lines per
+  // piece and every line is pulled from the fabric twice, 18 us apart -- too long for the XCD's L2 to
+  // keep it (profiles/r1m_pmc_memory_side.txt: 227 MB read per scan for 149 MB of input).  The first
+  // and the last batch of a row may therefore be partial.
+  static_assert(LN == 1, "line-aligned batching assumes one image row per wavefront");
+  const int a0 = GA_ROW_ALIGN ? (int)(((reinterpret_cast<uintptr_t>(x) >> 2) + (uintptr_t)vb[0]) & (uintptr_t)(SBH - 1)) : 0;
+  const int nb = (W + a0 + SBH - 1) / SBH;
   float Ap[DPL], m = 0.f;
 #pragma unroll
   for (int i = 0; i < DPL; i++) Ap[i] = 0.f;
@@ -94,7 +106,8 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   // guard every later use of its registers with vmcnt(0).
   constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;      // pieces per lane and image row
   float xpre[LN][NPC][4], wpre[LN][4];       // (plain floats: an f4 array carried around the loop stays in scratch)
-  auto batch_col = [&](int b) { return (desc ? W - (b + 1) * SBH : b * SBH) + 4 * piece; };
+  auto batch_col0 = [&](int b) { return (desc ? nb - 1 - b : b) * SBH - a0; };     // column of the batch's first element (may be < 0)
+  auto batch_col = [&](int b) { return batch_col0(b) + 4 * piece; };
   auto prefetch = [&](int b) {
     int wq = batch_col(b < nb ? b : nb - 1);
     wq = wq < 0 ? 0 : (wq > W - 4 ? W - 4 : wq);
@@ -130,16 +143,21 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   };
 
   prefetch(0);
+  bool started = false;                    // a position of this row has been visited (uniform)
   for (int b = 0; b < nb; b++) {
     const int wq = batch_col(b);
     const bool col_ok = wq >= 0 && wq < W;
+    const int bc0 = batch_col0(b);
     commit(b);
     GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
     prefetch(b + 1);
 #pragma unroll
     for (int kq = 0; kq < C::PP; kq++) {
-      if (b * SBH + 4 * kq < W) {
-        const int cq = desc ? C::PP - 1 - kq : kq;
+      const int cq = desc ? C::PP - 1 - kq : kq;
+      const int gc = bc0 + 4 * cq;           // image column of this group of 4 positions (W % 4 == 0: in or out as a whole)
+      if (gc >= 0 && gc < W) {
+        const bool first_group = !started;
+        started = true;
         f4 xv[DPL], wv[5], ov[DPL];
 #pragma unroll
         for (int i = 0; i < DPL; i++) {
@@ -156,7 +174,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
           for (int i = 0; i < DPL; i++) xs[i] = f4_get(xv[i], kk);
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
-          fwd_step<16, DPL, FULL>(xs, w, Ap, m, b == 0 && kq == 0 && k == 0, c, D);
+          fwd_step<16, DPL, FULL>(xs, w, Ap, m, k == 0 && first_group, c, D);
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Ap[i]);
         }
@@ -222,7 +240,10 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
     gbo[q] = (i64)s * 5 * geo.HW + (i64)h * W;
     kbo[q] = (i64)s * geo.HW + (i64)h * W;
   }
-  const int nb = (W + SBH - 1) / SBH;
+  // line-aligned batches, see sga_row_fwd (alignment taken from the gradOut volume, the widest stream)
+  static_assert(LN == 1, "line-aligned batching assumes one image row per wavefront");
+  const int a0 = GA_ROW_ALIGN ? (int)(((reinterpret_cast<uintptr_t>(gout) >> 2) + (uintptr_t)vb[0]) & (uintptr_t)(SBH - 1)) : 0;
+  const int nb = (W + a0 + SBH - 1) / SBH;
   float Gn[DPL], wn[5], sgn = 0.f;
 #pragma unroll
   for (int i = 0; i < DPL; i++) Gn[i] = 0.f;
@@ -237,7 +258,8 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;
   float gpre[LN][NPC][4], wpre[LN][4];
   uint32_t mpre[LN][NPC], kpre[LN][2];
-  auto batch_col = [&](int b) { return (desc ? W - (b + 1) * SBH : b * SBH) + 4 * piece; };
+  auto batch_col0 = [&](int b) { return (desc ? nb - 1 - b : b) * SBH - a0; };
+  auto batch_col = [&](int b) { return batch_col0(b) + 4 * piece; };
   auto prefetch = [&](int b) {
     int wq = batch_col(b < nb ? b : nb - 1);
     wq = wq < 0 ? 0 : (wq > W - 4 ? W - 4 : wq);
@@ -282,16 +304,21 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   };
 
   prefetch(0);
+  bool started = false;
   for (int b = 0; b < nb; b++) {
     const int wq = batch_col(b);
     const bool col_ok = wq >= 0 && wq < W;
+    const int bc0 = batch_col0(b);
     commit(b);
     GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain
     prefetch(b + 1);
 #pragma unroll
     for (int kq = 0; kq < C::PP; kq++) {
-      if (b * SBH + 4 * kq < W) {
-        const int cq = desc ? C::PP - 1 - kq : kq;
+      const int cq = desc ? C::PP - 1 - kq : kq;
+      const int gc = bc0 + 4 * cq;
+      if (gc >= 0 && gc < W) {
+        const bool first_group = !started;
+        started = true;
         f4 gov[DPL], wv[5], ov[DPL];
         uint32_t mw[DPL];
 #pragma unroll
@@ -316,7 +343,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
           const int kpv = (int)(((kk < 2 ? k01 : k23) >> (16 * (kk & 1))) & 0xffffu);
-          bwdg_step<16, DPL, uint8_t>(go, mk, Gn, wn, sgn, w, kpv, !(b == 0 && kq == 0 && k == 0), c, D, dir);
+          bwdg_step<16, DPL, uint8_t>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]);
         }
