@@ -299,10 +299,13 @@ int col_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const floa
   const size_t smem = col_smem_bwdg(D);
   const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
   // the adjoint of `down` (0) walks rows upwards (H-1..0), of `up` (1) downwards
+  const bool m16 = W % 16 == 0 && aligned16(mask);
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
-    if (dir == 1) GA_LAUNCH_SMEM((sga_col_bwdg<P, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
-    else GA_LAUNCH_SMEM((sga_col_bwdg<P, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);          \
+    if (dir == 1 && m16) GA_LAUNCH_SMEM((sga_col_bwdg<P, true, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
+    else if (dir == 1) GA_LAUNCH_SMEM((sga_col_bwdg<P, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);   \
+    else if (m16) GA_LAUNCH_SMEM((sga_col_bwdg<P, false, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);        \
+    else GA_LAUNCH_SMEM((sga_col_bwdg<P, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);                \
   }
   GA_ROW_DPLS(X)
 #undef X
