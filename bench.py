@@ -132,33 +132,78 @@ def stage_timings(inp, iters=5):
     return res
 
 
+# which kernels make up one launch of each family (names as in profiles/traffic_pmc.json)
+_FAMILY_KERNELS = {
+    "sga_scan_fwd": [["sga_col_fwd<5, true, true>"], ["sga_col_fwd<5, false, true>"],
+                     ["sga_row_fwd<5, 32, 4, 1, false, true>"], ["sga_row_fwd<5, 32, 4, 1, true, true>"]],
+    "sga_merge_argmax": [["sga_merge_px4"]],
+    "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
+                     ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
+    "sga_bwd_point": [["sga_bwd_point<4>"]],
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad<2>", "lga_apply_dma<2, true>"]],
+    "lga_apply (fwd pass)": [["lga_apply_dma<2, false>"]],
+}
+
+
+def pmc_traffic():
+    """Per-kernel traffic (bytes per dispatch at the L2 <-> fabric boundary) from the committed rocprofv3 --pmc
+    passes (profiles/traffic_pmc.json, made by scripts/gpu_pmc2.sh + scripts/pmc_traffic.py on an MI355X with
+    this workload).  Counters cannot be collected inside the timed run, hence the file; None when it is absent."""
+    fn = os.path.join(ROOT, "profiles", "traffic_pmc.json")
+    try:
+        with open(fn) as f:
+            return json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _family_traffic(name, kern):
+    """Mean traffic of one launch of the family (a launch = the kernels of one inner list)."""
+    if kern is None:
+        return None
+    tot, n = 0, 0
+    for launch in _FAMILY_KERNELS[name]:
+        try:
+            tot += sum(kern[k]["read_bytes"] + kern[k]["write_bytes"] for k in launch)
+        except KeyError:
+            return None
+        n += 1
+    return int(tot / n)
+
+
 def roofline_from_stages(stages):
-    """Dominant kernel family = the one with the largest time share of a step.  `achieved` =
-    that family's algorithmic bytes (op-level figure of SURVEY 8d divided over its launches;
-    SGA backward = 3V+8G is split half to the four adjoint scans, half to the per-pixel kernel)
-    / its average launch duration."""
+    """HBM roofline per kernel family and for the dominant one (largest time share of a step).
+    `achieved` = the family's algorithmic bytes per launch / its average launch duration.  The op-level
+    figures of SURVEY 8d are split by which kernel touches the API-level tensor: SGA forward 2V+4G =
+    4 scans x (V/4 + G) [x, guidance] + merge V [out]; SGA backward 3V+8G = 4 adjoint scans x V/4 [gradOut] +
+    per-pixel kernel 2V+8G [x, guidance in; gradInput, guidance grads out]; an LGA pass is half of its op.
+    `traffic` = measured bytes per launch from the PMC passes (pmc_traffic())."""
     fam = {
-        "sga_scan_fwd": ([k for k in stages if k.startswith("sga_scan_fwd_")], ALG_BYTES["sga_fwd"] / 4),
-        "sga_bwd_scan": ([k for k in stages if k.startswith("sga_bwd_scan_")], ALG_BYTES["sga_bwd"] / 8),
-        "sga_bwd_point": (["sga_bwd_point"], ALG_BYTES["sga_bwd"] / 2),
-        "lga_apply+filter_grad (bwd pass)": (["lga_bwd_pass"], ALG_BYTES["lga2_bwd"] / 2),
-        "lga_apply (fwd pass)": (["lga_fwd_pass"], ALG_BYTES["lga2_fwd"] / 2),
+        "sga_scan_fwd": ([k for k in stages if k.startswith("sga_scan_fwd_")], _V / 4 + _G, 1),
+        "sga_merge_argmax": (["sga_merge_argmax"], _V, 1),
+        "sga_bwd_scan": ([k for k in stages if k.startswith("sga_bwd_scan_")], _V / 4, 1),
+        "sga_bwd_point": (["sga_bwd_point"], 2 * _V + 8 * _G, 1),
+        "lga_apply+filter_grad (bwd pass)": (["lga_bwd_pass"], ALG_BYTES["lga2_bwd"] / 2, 2),
+        "lga_apply (fwd pass)": (["lga_fwd_pass"], ALG_BYTES["lga2_fwd"] / 2, 2),
     }
-    # launches per step: 4 scans fwd, 4 bwd, 2 lga fwd passes, 2 lga bwd passes
-    mult = {"sga_scan_fwd": 1, "sga_bwd_scan": 1, "sga_bwd_point": 1, "lga_apply+filter_grad (bwd pass)": 2,
-            "lga_apply (fwd pass)": 2}
-    best, best_t = None, -1.0
-    for name, (keys, _) in fam.items():
-        t = sum(stages[k] for k in keys) * mult[name]
-        if t > best_t:
-            best, best_t = name, t
-    keys, bytes_per_launch = fam[best]
-    avg_ms = sum(stages[k] for k in keys) / len(keys)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": best, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "alg_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
-            "traffic": None}
+    kern = pmc_traffic()
+    table, best, best_t = [], None, -1.0
+    for name, (keys, bytes_per_launch, mult) in fam.items():
+        avg_ms = sum(stages[k] for k in keys) / len(keys)
+        step_ms = sum(stages[k] for k in keys) * mult
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        row = {"kernel": name, "launches_per_step": len(keys) * mult, "avg_launch_ms": round(avg_ms, 4),
+               "alg_bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 1),
+               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _family_traffic(name, kern)}
+        table.append(row)
+        if step_ms > best_t:
+            best, best_t = row, step_ms
+    return {"bound": "hbm", "kernel": best["kernel"], "achieved": best["achieved"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": best["frac"], "alg_bytes_per_launch": best["alg_bytes_per_launch"],
+            "avg_launch_ms": best["avg_launch_ms"], "traffic": best["traffic"],
+            "traffic_source": "profiles/traffic_pmc.json (rocprofv3 --pmc TCC_EA0 request counters x request size, "
+                              "bytes per launch, Infinity-Cache hits included)" if best["traffic"] else None,
+            "families": table}
 
 
 def cpu_baseline():

@@ -24,7 +24,10 @@
 namespace ga {
 
 // rows per wavefront (LN) x positions per staged batch (SBH): LDS per wave bounds residency
-constexpr int ROW_SBH_F = 32, ROW_PAD_F = 4, ROW_LN_F = 1;   // forward: the A tile overwrites the x tile (9.8 KB per row at D=65)
+#ifndef GA_ROW_LN_F
+#define GA_ROW_LN_F 1
+#endif
+constexpr int ROW_SBH_F = 32, ROW_PAD_F = 4, ROW_LN_F = GA_ROW_LN_F;   // forward: the A tile overwrites the x tile (9.8 KB per row at D=65)
 constexpr size_t ROW_SMEM_MAX = 64 * 1024;
 
 inline size_t row_smem_fwd(int D)

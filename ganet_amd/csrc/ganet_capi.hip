@@ -239,7 +239,10 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
 }
 
 // ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
-constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = 1;   // adjoint scan: 1 tile + mask per row
+#ifndef GA_ROW_LN_B
+#define GA_ROW_LN_B 1
+#endif
+constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = GA_ROW_LN_B;   // adjoint scan: 1 tile + mask per row
 size_t row_smem_bwdg(int D)
 {
   const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH_B, ROW_PAD_B>::PP + 1) + 3) & ~(size_t)3;
@@ -409,14 +412,17 @@ int ew_grid(i64 n)
 }
 
 // ---- LGA dispatch -------------------------------------------------------------------
-// depth segments per tile for the wave-autonomous LGA kernels: enough work items (~7 per SIMD) for
-// the dispatcher to balance 1,024 SIMDs, segments no shorter than 32 planes (each item re-gathers
-// its pixel's filter taps and reads two extra halo planes)
-int lga_segments(int tiles, int D)
+// depth segments per tile for the wave-autonomous LGA kernels.  Every work item re-gathers its pixels'
+// filter taps (75 loads per lane; for the data-backward they come from 25 neighbouring pixels) and
+// reads two extra halo planes, so items should be as long as balance allows: measured at 240x624x193
+// (2,400 tiles; sweep of GANET_LGA_SEGS) the forward is fastest with ~4.5 items per SIMD (2 segments),
+// the data-backward with ~2.3 (1 segment); more segments cost 1-3 % each.
+int lga_segments(int tiles, int D, bool transposed)
 {
   int nseg = opts().lga_segs;
   if (nseg <= 0) {
-    nseg = (7 * 1024 + tiles - 1) / tiles;
+    const int target = transposed ? 2560 : 4608;
+    nseg = (target + tiles - 1) / tiles;
     const int cap = D / 32 > 1 ? D / 32 : 1;
     if (nseg > cap) nseg = cap;
   }
@@ -436,7 +442,7 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
     sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
     sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
     const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
-    sg.nseg = lga_segments((int)(tiles < (1 << 30) ? tiles : (1 << 30)), D);
+    sg.nseg = lga_segments((int)(tiles < (1 << 30) ? tiles : (1 << 30)), D, transposed);
     sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
     sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
     const i64 items = tiles * sg.nseg;

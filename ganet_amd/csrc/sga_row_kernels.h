@@ -89,7 +89,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   // piece and every line is pulled from the fabric twice, 18 us apart -- too long for the XCD's L2 to
   // keep it (profiles/r1m_pmc_memory_side.txt: 227 MB read per scan for 149 MB of input).  The first
   // and the last batch of a row may therefore be partial.
-  static_assert(LN == 1, "line-aligned batching assumes one image row per wavefront");
+  static_assert(LN == 1 || !GA_ROW_ALIGN, "line-aligned batching assumes one image row per wavefront");
   const int a0 = GA_ROW_ALIGN ? (int)(((reinterpret_cast<uintptr_t>(x) >> 2) + (uintptr_t)vb[0]) & (uintptr_t)(SBH - 1)) : 0;
   const int nb = (W + a0 + SBH - 1) / SBH;
   float Ap[DPL], m = 0.f;
@@ -241,7 +241,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
     kbo[q] = (i64)s * geo.HW + (i64)h * W;
   }
   // line-aligned batches, see sga_row_fwd (alignment taken from the gradOut volume, the widest stream)
-  static_assert(LN == 1, "line-aligned batching assumes one image row per wavefront");
+  static_assert(LN == 1 || !GA_ROW_ALIGN, "line-aligned batching assumes one image row per wavefront");
   const int a0 = GA_ROW_ALIGN ? (int)(((reinterpret_cast<uintptr_t>(gout) >> 2) + (uintptr_t)vb[0]) & (uintptr_t)(SBH - 1)) : 0;
   const int nb = (W + a0 + SBH - 1) / SBH;
   float Gn[DPL], wn[5], sgn = 0.f;
