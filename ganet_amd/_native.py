@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -34,6 +34,10 @@ _PROTOS = {
     "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_disparity_regression_forward": [_P] * 2 + [_I] * 4 + [_P],
     "ganet_disparity_regression_backward": [_P] * 2 + [_I] * 4 + [_P],
+    "ganet_l1_normalize_forward": [_P] * 5 + [_I] * 6 + [_P],
+    "ganet_l1_normalize_backward": [_P] * 6 + [_I] * 6 + [_P],
+    "ganet_norm_disparity_regression_forward": [_P] * 3 + [_I] * 4 + [_P],
+    "ganet_norm_disparity_regression_backward": [_P] * 5 + [_I] * 4 + [_P],
     "ganet_selftest_dpp": [_P, _P, _P],
 }
 EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])

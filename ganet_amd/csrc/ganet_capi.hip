@@ -764,6 +764,85 @@ GA_EXPORT int ganet_disparity_regression_backward(const float *grad_out, float *
   return check_launch("disparity regression backward");
 }
 
+// ---- callers' normalisations folded into single kernels ------------------------
+namespace {
+int check_norm(const char *who, int N, int G, int C, int K, int H, int W)
+{
+  if (N <= 0 || G <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "%s: non-positive size N=%d G=%d C=%d K=%d H=%d W=%d", who, N, G, C, K, H, W);
+  if (G > 4) return fail(GANET_E_UNSUPPORTED, "%s: at most 4 groups, got %d", who, G);
+  return GANET_OK;
+}
+}  // namespace
+
+GA_EXPORT int ganet_l1_normalize_forward(const float *x, float *y0, float *y1, float *y2, float *y3,
+                                         int N, int G, int C, int K, int H, int W, void *stream)
+{
+  GA_TRY(check_norm("ganet_l1_normalize_forward", N, G, C, K, H, W));
+  float *ys[4] = {y0, y1, y2, y3};
+  if (!x) return fail(GANET_E_INVALID, "ganet_l1_normalize_forward: null pointer");
+  NormPtrs p = {};
+  for (int g = 0; g < 4; g++) {
+    if (g < G && !ys[g]) return fail(GANET_E_INVALID, "ganet_l1_normalize_forward: null output %d", g);
+    p.y[g] = ys[g < G ? g : 0];
+  }
+  const i64 HW = (i64)H * W;
+  const dim3 grid(ew_grid((i64)N * G * C * HW)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 5) GA_LAUNCH((l1norm_fwd<5>), grid, block, st, x, p, N, G, C, K, HW);
+  else if (K == 75) GA_LAUNCH((l1norm_fwd<75>), grid, block, st, x, p, N, G, C, K, HW);
+  else GA_LAUNCH((l1norm_fwd<0>), grid, block, st, x, p, N, G, C, K, HW);
+  return check_launch("l1 normalise forward");
+}
+
+GA_EXPORT int ganet_l1_normalize_backward(const float *x, const float *gy0, const float *gy1,
+                                          const float *gy2, const float *gy3, float *grad_x,
+                                          int N, int G, int C, int K, int H, int W, void *stream)
+{
+  GA_TRY(check_norm("ganet_l1_normalize_backward", N, G, C, K, H, W));
+  const float *gs[4] = {gy0, gy1, gy2, gy3};
+  if (!x || !grad_x) return fail(GANET_E_INVALID, "ganet_l1_normalize_backward: null pointer");
+  NormPtrs p = {};
+  for (int g = 0; g < 4; g++) {
+    if (g < G && !gs[g]) return fail(GANET_E_INVALID, "ganet_l1_normalize_backward: null gradient %d", g);
+    p.gy[g] = gs[g < G ? g : 0];
+  }
+  const i64 HW = (i64)H * W;
+  const dim3 grid(ew_grid((i64)N * G * C * HW)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 5) GA_LAUNCH((l1norm_bwd<5>), grid, block, st, x, p, grad_x, N, G, C, K, HW);
+  else if (K == 75) GA_LAUNCH((l1norm_bwd<75>), grid, block, st, x, p, grad_x, N, G, C, K, HW);
+  else GA_LAUNCH((l1norm_bwd<0>), grid, block, st, x, p, grad_x, N, G, C, K, HW);
+  return check_launch("l1 normalise backward");
+}
+
+GA_EXPORT int ganet_norm_disparity_regression_forward(const float *x, float *out, float *snorm, int N,
+                                                      int Dn, int H, int W, void *stream)
+{
+  if (!x || !out || !snorm)
+    return fail(GANET_E_INVALID, "ganet_norm_disparity_regression_forward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_norm_disparity_regression_forward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(norm_disp_regression_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, out, snorm, N, Dn, HW);
+  return check_launch("normalised disparity regression forward");
+}
+
+GA_EXPORT int ganet_norm_disparity_regression_backward(const float *x, const float *out,
+                                                       const float *snorm, const float *grad_out,
+                                                       float *grad_x, int N, int Dn, int H, int W,
+                                                       void *stream)
+{
+  if (!x || !out || !snorm || !grad_out || !grad_x)
+    return fail(GANET_E_INVALID, "ganet_norm_disparity_regression_backward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_norm_disparity_regression_backward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(norm_disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, x, out, snorm,
+            grad_out, grad_x, N, Dn, HW);
+  return check_launch("normalised disparity regression backward");
+}
+
 GA_EXPORT int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream)
 {
   if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp: null pointer");

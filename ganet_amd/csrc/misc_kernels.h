@@ -86,4 +86,147 @@ disp_regression_bwd(const float *__restrict__ gout, float *__restrict__ gx, int 
   }
 }
 
+// =====================================================================================
+// Callers' pre-/post-ops folded into single kernels.  In the reference they
+// are chains of stock PyTorch kernels around the guided-aggregation ops:
+//   models/GANet_deep.py:263-268  split + view + F.normalize(p=1, dim=2) of the SGA guidance (x4)
+//   models/GANet_deep.py:235      F.normalize(p=1, dim=1) of the LGA filters
+//   models/GANet_deep.py:246-247  F.normalize(p=1, dim=1) of the aggregated volume + DisparityRegression
+// F.normalize(x, p=1, dim) = x / max(sum_dim |x|, eps), eps = 1e-12 (torch.nn.functional.normalize).
+// =====================================================================================
+constexpr float GA_NORM_EPS = 1e-12f;
+
+struct NormPtrs {
+  float *y[4];
+  const float *gy[4];
+};
+
+// x [N][G][C][K][HW] -> y_g [N][C][K][HW], g < G <= 4: L1-normalise over K (the SGABlock split: G = 4,
+// K = 5; LGA filters: G = C = 1, K = 3(2r+1)^2).  One lane per (n,g,c,pixel); the K values of a lane
+// stay in registers when K is a template constant, otherwise the lane walks its column twice.
+template <int KT>
+__global__ void __launch_bounds__(256)
+l1norm_fwd(const float *__restrict__ x, NormPtrs p, int N, int G, int C, int Krt, i64 HW)
+{
+  const int K = KT > 0 ? KT : Krt;
+  const i64 total = (i64)N * G * C * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const i64 o = idx / HW, pix = idx - o * HW;
+    const int c = (int)(o % C);
+    const int g = (int)((o / C) % G);
+    const i64 n = o / ((i64)C * G);
+    const float *xin = x + o * K * HW + pix;
+    float *yb = g == 0 ? p.y[0] : g == 1 ? p.y[1] : g == 2 ? p.y[2] : p.y[3];
+    float *yo = yb + (n * C + c) * K * HW + pix;
+    if (KT > 0) {
+      float v[KT > 0 ? KT : 1];
+      float sa = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; t++) { v[t] = xin[(i64)t * HW]; sa += fabsf(v[t]); }
+      const float sden = fmaxf(sa, GA_NORM_EPS);
+#pragma unroll
+      for (int t = 0; t < KT; t++) yo[(i64)t * HW] = v[t] / sden;
+    } else {
+      float sa = 0.f;
+      for (int t = 0; t < K; t++) sa += fabsf(xin[(i64)t * HW]);
+      const float sden = fmaxf(sa, GA_NORM_EPS);
+      for (int t = 0; t < K; t++) yo[(i64)t * HW] = xin[(i64)t * HW] / sden;
+    }
+  }
+}
+
+// adjoint: gx_t = (gy_t - sgn(x_t) * sum_u gy_u y_u) / s  with s = sum|x| (> eps); gy_t / eps where the norm was clamped
+template <int KT>
+__global__ void __launch_bounds__(256)
+l1norm_bwd(const float *__restrict__ x, NormPtrs p, float *__restrict__ gx, int N, int G, int C, int Krt, i64 HW)
+{
+  const int K = KT > 0 ? KT : Krt;
+  const i64 total = (i64)N * G * C * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    const i64 o = idx / HW, pix = idx - o * HW;
+    const int c = (int)(o % C);
+    const int g = (int)((o / C) % G);
+    const i64 n = o / ((i64)C * G);
+    const float *xin = x + o * K * HW + pix;
+    float *gxo = gx + o * K * HW + pix;
+    const float *gb = g == 0 ? p.gy[0] : g == 1 ? p.gy[1] : g == 2 ? p.gy[2] : p.gy[3];
+    const float *gyi = gb + (n * C + c) * K * HW + pix;
+    if (KT > 0) {
+      float v[KT > 0 ? KT : 1], gv[KT > 0 ? KT : 1];
+      float sa = 0.f, dot = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; t++) { v[t] = xin[(i64)t * HW]; gv[t] = gyi[(i64)t * HW]; sa += fabsf(v[t]); }
+      const bool clamped = sa < GA_NORM_EPS;
+      const float sden = fmaxf(sa, GA_NORM_EPS);
+#pragma unroll
+      for (int t = 0; t < KT; t++) dot = fmaf(gv[t], v[t] / sden, dot);
+      if (clamped) dot = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; t++) {
+        const float sg = v[t] > 0.f ? 1.f : (v[t] < 0.f ? -1.f : 0.f);
+        gxo[(i64)t * HW] = (gv[t] - sg * dot) / sden;
+      }
+    } else {
+      float sa = 0.f, dot = 0.f;
+      for (int t = 0; t < K; t++) sa += fabsf(xin[(i64)t * HW]);
+      const bool clamped = sa < GA_NORM_EPS;
+      const float sden = fmaxf(sa, GA_NORM_EPS);
+      for (int t = 0; t < K; t++) dot = fmaf(gyi[(i64)t * HW], xin[(i64)t * HW] / sden, dot);
+      if (clamped) dot = 0.f;
+      for (int t = 0; t < K; t++) {
+        const float xv = xin[(i64)t * HW];
+        const float sg = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f);
+        gxo[(i64)t * HW] = (gyi[(i64)t * HW] - sg * dot) / sden;
+      }
+    }
+  }
+}
+
+// out[n,h,w] = sum_d d * x[n,d,h,w] / max(sum_d |x[n,d,h,w]|, eps);  snorm[n,h,w] = that denominator
+// (F.normalize(x, p=1, dim=1) followed by DisparityRegression: one read of the volume instead of
+// norm + clamp + div + arange-product + sum).
+static __global__ void __launch_bounds__(256)
+norm_disp_regression_fwd(const float *__restrict__ x, float *__restrict__ out, float *__restrict__ snorm,
+                         int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / HW, pix = o - n * HW;
+    const float *xp = x + n * Dn * HW + pix;
+    float acc = 0.f, sa = 0.f;
+    for (int d = 0; d < Dn; d++) {
+      const float v = xp[(i64)d * HW];
+      acc = fmaf(v, (float)d, acc);
+      sa += fabsf(v);
+    }
+    const float sden = fmaxf(sa, GA_NORM_EPS);
+    out[o] = acc / sden;
+    snorm[o] = sden;
+  }
+}
+
+// gx[n,d,h,w] = gout * (d - out * sgn(x_d)) / s    (gout * d / eps where the norm was clamped)
+static __global__ void __launch_bounds__(256)
+norm_disp_regression_bwd(const float *__restrict__ x, const float *__restrict__ out,
+                         const float *__restrict__ snorm, const float *__restrict__ gout,
+                         float *__restrict__ gx, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * Dn * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 pix = o % HW;
+    const i64 r = o / HW;
+    const int d = (int)(r % Dn);
+    const i64 n = r / Dn;
+    const float xv = x[o];
+    const float sden = snorm[n * HW + pix];
+    const float ov = sden > GA_NORM_EPS ? out[n * HW + pix] : 0.f;
+    const float sg = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : 0.f);
+    gx[o] = gout[n * HW + pix] * (((float)d - ov * sg) / sden);
+  }
+}
+
 }  // namespace ga

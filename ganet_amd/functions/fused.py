@@ -1,0 +1,102 @@
+"""Callers' normalisations folded into single kernels.
+
+In the reference these are chains of stock PyTorch ops AROUND the guided-aggregation operators:
+  * SGABlock.forward   (models/GANet_deep.py:263-268): torch.split + view + 4 x F.normalize(p=1, dim=2)
+  * DispAgg.lga        (models/GANet_deep.py:235):     F.normalize(g, p=1, dim=1)
+  * DispAgg.forward    (models/GANet_deep.py:246-247): F.normalize(x, p=1, dim=1) + DisparityRegression
+They sit BESIDE the drop-in API (libs/GANet/... keeps the reference's call forms unchanged): a model opts in by
+calling GuidedSGA / NormalizedLGA2 / DispAggTail from ganet_amd.modules.fused instead of the op chains.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _native
+from .GANet import _check, _p, _stream
+
+__all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters"]
+
+
+def _lib():
+    return _native.lib()
+
+
+class L1NormalizeGroupsFunction(Function):
+    """x [N, G*C*K, H, W] (= [N,G,C,K,H,W]) -> G tensors [N,C,K,H,W], each L1-normalised over K.
+
+    G=4, K=5 is SGABlock's split/view/normalize of the guidance; G=C=1 is F.normalize(g, p=1, dim=1)."""
+
+    @staticmethod
+    def forward(ctx, x, G, C, K):
+        _check(x)
+        if x.dim() != 4 or x.shape[1] != G * C * K:
+            raise ValueError(f"expected [N,{G * C * K},H,W], got {tuple(x.shape)}")
+        if not 1 <= G <= 4:
+            raise ValueError("1 <= G <= 4")
+        N, _, H, W = x.shape
+        ctx.dims = (N, G, C, K, H, W)
+        with torch.cuda.device_of(x):
+            y = torch.empty((G, N, C, K, H, W), dtype=x.dtype, device=x.device)
+            ys = [y[g] for g in range(G)]
+            ptrs = [_p(t) for t in ys] + [None] * (4 - G)
+            _lib().call("ganet_l1_normalize_forward", _p(x), *ptrs, N, G, C, K, H, W, _stream())
+        ctx.save_for_backward(x)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, = ctx.saved_tensors
+        N, G, C, K, H, W = ctx.dims
+        gs = []
+        for g in grads:
+            g = torch.zeros((N, C, K, H, W), dtype=x.dtype, device=x.device) if g is None else g.contiguous()
+            _check(g)
+            gs.append(g)
+        with torch.cuda.device_of(x):
+            gx = torch.empty_like(x)
+            ptrs = [_p(t) for t in gs] + [None] * (4 - G)
+            _lib().call("ganet_l1_normalize_backward", _p(x), *ptrs, _p(gx), N, G, C, K, H, W, _stream())
+        return gx, None, None, None
+
+
+def normalize_guidance(g, channels):
+    """[N, 20*channels, H, W] -> (k1, k2, k3, k4), each [N, channels, 5, H, W] and L1-normalised over dim 2
+    (what SGABlock.forward computes with split + view + F.normalize, models/GANet_deep.py:263-268)."""
+    return L1NormalizeGroupsFunction.apply(g.contiguous(), 4, channels, 5)
+
+
+def normalize_filters(g):
+    """F.normalize(g, p=1, dim=1) for LGA filters [N, K, H, W] (models/GANet_deep.py:235)."""
+    N, K, H, W = g.shape
+    (y,) = L1NormalizeGroupsFunction.apply(g.contiguous(), 1, 1, K)
+    return y.view(N, K, H, W)
+
+
+class NormDisparityRegressionFunction(Function):
+    """out[N,H,W] = sum_d d * x[N,D,H,W] / max(sum_d |x|, 1e-12): F.normalize(x, p=1, dim=1) followed by
+    DisparityRegression (models/GANet_deep.py:246-247, modules/GANet.py:136-148) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, ndisp):
+        _check(x)
+        if x.dim() != 4 or x.shape[1] != ndisp:
+            raise ValueError(f"expected [N,{ndisp},H,W], got {tuple(x.shape)}")
+        N, D, H, W = x.shape
+        ctx.dims = (N, D, H, W)
+        with torch.cuda.device_of(x):
+            out = torch.empty((N, H, W), dtype=x.dtype, device=x.device)
+            snorm = torch.empty_like(out)
+            _lib().call("ganet_norm_disparity_regression_forward", _p(x), _p(out), _p(snorm), N, D, H, W, _stream())
+        ctx.save_for_backward(x, out, snorm)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, out, snorm = ctx.saved_tensors
+        g = grad_out.contiguous()
+        _check(g)
+        N, D, H, W = ctx.dims
+        with torch.cuda.device_of(g):
+            gx = torch.empty_like(x)
+            _lib().call("ganet_norm_disparity_regression_backward", _p(x), _p(out), _p(snorm), _p(g), _p(gx),
+                        N, D, H, W, _stream())
+        return gx, None

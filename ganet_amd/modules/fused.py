@@ -1,0 +1,58 @@
+"""Fused forms of the op chains around SGA / LGA in models/GANet_deep.py.  Opt-in: the
+reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
+import torch
+from torch.nn.modules.module import Module
+
+from ..functions.fused import NormDisparityRegressionFunction, normalize_filters, normalize_guidance
+from ..functions.GANet import Lga2Function, SgaFunction
+
+__all__ = ["GuidedSGA", "NormalizedLGA2", "NormDisparityRegression", "DispAggTail"]
+
+
+class GuidedSGA(Module):
+    """SGA on the RAW guidance: forward(x [N,C,D,H,W], g [N,20C,H,W]) == SGABlock.forward lines
+    models/GANet_deep.py:263-269 (split, view, 4 x F.normalize(p=1, dim=2), SGA)."""
+
+    def forward(self, x, g):
+        k1, k2, k3, k4 = normalize_guidance(g, x.shape[1])
+        return SgaFunction.apply(x, k1, k2, k3, k4)
+
+
+class NormalizedLGA2(Module):
+    """DispAgg.lga (models/GANet_deep.py:234-237): LGA2(x, F.normalize(g, p=1, dim=1))."""
+
+    def __init__(self, radius=2):
+        super().__init__()
+        self.radius = radius
+
+    def forward(self, x, g):
+        return Lga2Function.apply(x, normalize_filters(g), self.radius)
+
+
+class NormDisparityRegression(Module):
+    """F.normalize(x, p=1, dim=1) + DisparityRegression(maxdisp) in one pass (models/GANet_deep.py:246-247)."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp + 1
+
+    def forward(self, x):
+        return NormDisparityRegressionFunction.apply(x.contiguous(), self.maxdisp)
+
+
+class DispAggTail(Module):
+    """DispAgg.forward after the trilinear upsampling (models/GANet_deep.py:243-247):
+    lga(x, lg1) -> Softmin(dim=1) -> lga(x, lg2) -> F.normalize(p=1, dim=1) -> DisparityRegression."""
+
+    def __init__(self, maxdisp=192, radius=2):
+        super().__init__()
+        self.lga = NormalizedLGA2(radius)
+        self.softmax = torch.nn.Softmin(dim=1)
+        self.disparity = NormDisparityRegression(maxdisp)
+
+    def forward(self, x, lg1, lg2):
+        assert lg1.size() == lg2.size()
+        x = self.lga(x, lg1)
+        x = self.softmax(x)
+        x = self.lga(x, lg2)
+        return self.disparity(x)

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 2
+#define GANET_ABI_VERSION 3
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -142,6 +142,29 @@ int ganet_disparity_regression_forward(const float *x, float *out,
                                        int N, int Dn, int H, int W, void *stream);
 int ganet_disparity_regression_backward(const float *grad_out, float *grad_x,
                                         int N, int Dn, int H, int W, void *stream);
+
+/* ------------------------------------------------- callers' normalisations ---- */
+
+/* L1 normalisation over a strided channel axis, F.normalize(x, p=1, dim) = x / max(sum|x|, 1e-12).
+ * x [N][G][C][K][H][W]  ->  y_g [N][C][K][H][W] for g < G (G <= 4; unused outputs may be NULL).
+ * G = 4, K = 5 replaces SGABlock's torch.split + view + 4 x F.normalize(p=1, dim=2) of the guidance
+ * (models/GANet_deep.py:263-268; ~16 stock kernels); G = C = 1, K = 3(2r+1)^2 replaces
+ * F.normalize(g, p=1, dim=1) of the LGA filters (models/GANet_deep.py:235).
+ * backward: grad_x [N][G][C][K][H][W] from x and the G gradients wrt y_g (autograd of the same ops). */
+int ganet_l1_normalize_forward(const float *x, float *y0, float *y1, float *y2, float *y3,
+                               int N, int G, int C, int K, int H, int W, void *stream);
+int ganet_l1_normalize_backward(const float *x, const float *gy0, const float *gy1,
+                                const float *gy2, const float *gy3, float *grad_x,
+                                int N, int G, int C, int K, int H, int W, void *stream);
+
+/* out [N,H,W] = sum_d d * x[N,Dn,H,W] / s,  s = snorm [N,H,W] = max(sum_d |x|, 1e-12).
+ * Replaces: F.normalize(x, p=1, dim=1) followed by DisparityRegression at the end of DispAgg.forward
+ * (models/GANet_deep.py:246-247): one pass over the volume instead of five.  backward needs x, out, snorm. */
+int ganet_norm_disparity_regression_forward(const float *x, float *out, float *snorm,
+                                            int N, int Dn, int H, int W, void *stream);
+int ganet_norm_disparity_regression_backward(const float *x, const float *out, const float *snorm,
+                                             const float *grad_out, float *grad_x,
+                                             int N, int Dn, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------- diagnostics ---- */
 

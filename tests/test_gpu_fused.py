@@ -1,0 +1,113 @@
+"""GPU parity of the fused caller-side op chains: ganet_amd.modules.fused vs the reference's own
+torch statements on the CPU (oracle/fused_ref.py; LGA/SGA through the C oracle)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from oracle import fused_ref as fr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 33, 12, 24), (2, 3, 17, 9, 16)])
+def test_guided_sga_matches_sgablock_lines(torch_mod, port_oracle, shape):
+    """GuidedSGA(x, g_raw) == split/view/normalize x4 + SGA (models/GANet_deep.py:263-269), forward and backward."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import GuidedSGA
+    N, C, D, H, W = shape
+    torch.manual_seed(5)
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    g = torch.randn(N, 20 * C, H, W, device="cuda", requires_grad=True)
+    go = torch.randn(shape, device="cuda")
+    out = GuidedSGA()(x, g)
+    out.backward(go)
+    torch.cuda.synchronize()
+    # CPU: the reference's statements for the guidance, the C oracle for SGA, autograd for the normalisation
+    gc = g.detach().cpu().requires_grad_()
+    ks = fr.sgablock_guidance(gc, C)
+    kn = [np.ascontiguousarray(_np(k)) for k in ks]
+    o_out, o_tmp, o_mask = port_oracle.sga_forward(_np(x), *kn)
+    o_g = port_oracle.sga_backward(_np(x), *kn, o_tmp, o_mask, _np(go))
+    torch.autograd.backward(ks, [torch.from_numpy(np.ascontiguousarray(a)) for a in o_g[1:]])
+    # the kernel's normalised taps can differ from torch-CPU's in the last bit (order of the 5-term sum),
+    # so the forward is compared at the op tolerance, not bit-exactly
+    assert np.abs(_np(out) - o_out).max() <= pc.TOL
+    assert np.abs(_np(x.grad) - o_g[0]).max() <= pc.TOL
+    assert np.abs(_np(g.grad) - gc.grad.numpy()).max() <= pc.TOL
+
+
+def test_normalize_functions_match_torch(torch_mod):
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.functions.fused import normalize_filters, normalize_guidance
+    torch.manual_seed(9)
+    g = torch.randn(2, 75, 20, 24, device="cuda", requires_grad=True)
+    gy = torch.randn(2, 75, 20, 24, device="cuda")
+    y = normalize_filters(g)
+    y.backward(gy)
+    gc = g.detach().cpu().requires_grad_()
+    w = F.normalize(gc, p=1, dim=1)
+    w.backward(gy.cpu())
+    np.testing.assert_allclose(_np(y), _np(w), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(_np(g.grad), gc.grad.numpy(), rtol=1e-4, atol=1e-6)
+    # only two of the four guidance outputs receive a gradient: the others count as zero
+    g2 = torch.randn(1, 40, 6, 8, device="cuda", requires_grad=True)
+    ks = normalize_guidance(g2, 2)
+    (ks[0].sum() + 2 * ks[3].sum()).backward()
+    g2c = g2.detach().cpu().requires_grad_()
+    kc = fr.sgablock_guidance(g2c, 2)
+    (kc[0].sum() + 2 * kc[3].sum()).backward()
+    np.testing.assert_allclose(_np(g2.grad), g2c.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_dispagg_tail_matches_reference_statements(torch_mod, port_oracle):
+    """DispAggTail == models/GANet_deep.py:243-247 on a small volume (maxdisp 11), forward and all three gradients."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import DispAggTail
+    torch.manual_seed(3)
+    maxdisp, H, W = 11, 14, 36
+    x = torch.randn(1, maxdisp + 1, H, W, device="cuda", requires_grad=True)
+    lg1 = torch.randn(1, 75, H, W, device="cuda", requires_grad=True)
+    lg2 = torch.randn(1, 75, H, W, device="cuda", requires_grad=True)
+    go = torch.randn(1, H, W, device="cuda")
+    out = DispAggTail(maxdisp)(x, lg1, lg2)
+    out.backward(go)
+    torch.cuda.synchronize()
+    xc, l1c, l2c = (t.detach().cpu().requires_grad_() for t in (x, lg1, lg2))
+    want = fr.dispagg_tail(xc, l1c, l2c, maxdisp, port_oracle)
+    want.backward(go.cpu())
+    np.testing.assert_allclose(_np(out), want.detach().numpy(), rtol=1e-5, atol=1e-4)
+    # five chained ops (two of them divisions by small L1 norms) amplify fp32 rounding: the gradients reach
+    # |g| ~ 10^1..10^2 here, so the bar is 1e-4 RELATIVE to the largest gradient entry (>= 1e-4 absolute)
+    for got, ref in ((x.grad, xc.grad), (lg1.grad, l1c.grad), (lg2.grad, l2c.grad)):
+        scale = max(1.0, float(np.abs(ref.numpy()).max()))
+        assert np.abs(_np(got) - ref.numpy()).max() <= pc.TOL * scale, (np.abs(_np(got) - ref.numpy()).max(), scale)
+
+
+def test_norm_regression_full_size(torch_mod):
+    """[1,193,240,624] (cfg2): against torch's own ops on the GPU (same statements as the reference)."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.modules.fused import NormDisparityRegression
+    torch.manual_seed(1)
+    x = torch.softmax(-torch.randn(1, 193, 240, 624, device="cuda"), dim=1).requires_grad_()
+    go = torch.randn(1, 240, 624, device="cuda")
+    out = NormDisparityRegression(192)(x)
+    out.backward(go)
+    x2 = x.detach().clone().requires_grad_()
+    disp = torch.arange(193, device="cuda", dtype=torch.float32).view(1, 193, 1, 1)
+    ref = torch.sum(F.normalize(x2, p=1, dim=1) * disp, 1)
+    ref.backward(go)
+    np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-4)
+    assert (x.grad - x2.grad).abs().max().item() <= 1e-3 * x2.grad.abs().max().item()

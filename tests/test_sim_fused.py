@@ -1,0 +1,91 @@
+"""Kernel logic of the fused caller-side normalisations on the CPU emulator build, through the
+C ABI, against the reference's own torch statements executed on the CPU (oracle/fused_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fused_ref as fr
+
+RTOL, ATOL = 1e-5, 1e-6      # fp32 elementwise ops: the only freedom is summation order / fma contraction
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from sim_util import sim_api
+    return sim_api()
+
+
+def _p(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 2, 3, 4), (2, 3, 5, 7), (1, 1, 1, 1)])
+def test_guidance_normalize_forward_backward(sim, N, C, H, W):
+    rng = np.random.default_rng(N * 100 + C)
+    g = rng.standard_normal((N, 20 * C, H, W)).astype(np.float32)
+    g[0, 0:5, 0, 0] = 0.0                                  # an all-zero tap group: the clamped-norm branch
+    g[0, 7, 0, 0] = 0.0                                    # sgn(0) = 0
+    gys = [rng.standard_normal((N, C, 5, H, W)).astype(np.float32) for _ in range(4)]
+    ys = [np.full((N, C, 5, H, W), np.nan, np.float32) for _ in range(4)]
+    sim.call("ganet_l1_normalize_forward", _p(g), *[_p(y) for y in ys], N, 4, C, 5, H, W, None)
+    tg = torch.from_numpy(g).requires_grad_()
+    want = fr.sgablock_guidance(tg, C)
+    for y, w in zip(ys, want):
+        np.testing.assert_allclose(y, w.detach().numpy(), rtol=RTOL, atol=ATOL)
+    torch.autograd.backward(want, [torch.from_numpy(a) for a in gys])
+    gx = np.full_like(g, np.nan)
+    sim.call("ganet_l1_normalize_backward", _p(g), *[_p(a) for a in gys], _p(gx), N, 4, C, 5, H, W, None)
+    wg = tg.grad.numpy()
+    ok = np.abs(wg) < 1e6                                  # (clamped group: gradient = gy / 1e-12, compare relatively)
+    np.testing.assert_allclose(gx[ok], wg[ok], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gx[~ok], wg[~ok], rtol=1e-4)
+
+
+@pytest.mark.parametrize("K", [75, 27, 5, 9])
+def test_filter_normalize_any_K(sim, K):
+    rng = np.random.default_rng(K)
+    N, H, W = 2, 4, 6
+    g = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
+    y = np.full_like(g, np.nan)
+    sim.call("ganet_l1_normalize_forward", _p(g), _p(y), None, None, None, N, 1, 1, K, H, W, None)
+    tg = torch.from_numpy(g).requires_grad_()
+    want = fr.lga_filters(tg)
+    np.testing.assert_allclose(y, want.detach().numpy(), rtol=RTOL, atol=ATOL)
+    want.backward(torch.from_numpy(gy))
+    gx = np.full_like(g, np.nan)
+    sim.call("ganet_l1_normalize_backward", _p(g), _p(gy), None, None, None, _p(gx), N, 1, 1, K, H, W, None)
+    np.testing.assert_allclose(gx, tg.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,maxdisp,H,W", [(1, 8, 3, 5), (2, 23, 4, 4), (1, 192, 2, 3)])
+def test_norm_disparity_regression(sim, N, maxdisp, H, W):
+    rng = np.random.default_rng(maxdisp)
+    D = maxdisp + 1
+    x = rng.random((N, D, H, W)).astype(np.float32)        # post-LGA probabilities are non-negative ...
+    x[0, :, 0, 0] = rng.standard_normal(D)                 # ... but signs must work too
+    x[0, 3, 0, 1] = 0.0
+    go = rng.standard_normal((N, H, W)).astype(np.float32)
+    out = np.full((N, H, W), np.nan, np.float32)
+    sn = np.full((N, H, W), np.nan, np.float32)
+    sim.call("ganet_norm_disparity_regression_forward", _p(x), _p(out), _p(sn), N, D, H, W, None)
+    tx = torch.from_numpy(x).requires_grad_()
+    want = fr.norm_regression(tx, maxdisp)
+    np.testing.assert_allclose(out, want.detach().numpy(), rtol=1e-5, atol=1e-4)   # disparities up to 192: 1e-4 px
+    np.testing.assert_allclose(sn, np.abs(x).sum(1), rtol=1e-5)
+    want.backward(torch.from_numpy(go))
+    gx = np.full_like(x, np.nan)
+    sim.call("ganet_norm_disparity_regression_backward", _p(x), _p(out), _p(sn), _p(go), _p(gx), N, D, H, W, None)
+    np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_argument_errors(sim):
+    from ganet_amd._native import GanetError
+    a = np.zeros((1, 20, 2, 2), np.float32)
+    with pytest.raises(GanetError, match="null"):
+        sim.call("ganet_l1_normalize_forward", None, _p(a), None, None, None, 1, 1, 1, 5, 2, 2, None)
+    with pytest.raises(GanetError, match="groups"):
+        sim.call("ganet_l1_normalize_forward", _p(a), _p(a), _p(a), _p(a), _p(a), 1, 5, 1, 5, 2, 2, None)
+    with pytest.raises(GanetError, match="null output 1"):
+        sim.call("ganet_l1_normalize_forward", _p(a), _p(a), None, None, None, 1, 2, 1, 5, 2, 2, None)
