@@ -66,6 +66,7 @@ struct Options {
   int lga_segs = 0;   // depth segments per tile for those kernels (0 = automatic)
   int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
   int colblock = 1;     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
+  int point_block = 256;   // threads per block of the per-pixel gradient kernel
   int merge4 = 1;       // merge + arg-max: four pixels per lane (16-byte requests)
   int block_v = 128;
   int block_h = 64;
@@ -87,6 +88,7 @@ void load_env_options()
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
   geti("GANET_SGA_MERGE4", g_opt.merge4);
+  geti("GANET_SGA_POINT_BLOCK", g_opt.point_block);
   geti("GANET_SGA_BLOCK_V", g_opt.block_v);
   geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
@@ -396,10 +398,16 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
               int accumulate, hipStream_t st)
 {
   const i64 npix = (i64)N * C * H * W;
+  int pb = opts().point_block;
+  if (pb != 64 && pb != 128 && pb != 256) pb = 256;
+  i64 gsz = (npix + pb - 1) / pb;
+  const i64 gmax = (i64)256 * 32 * (256 / pb);
+  if (gsz > gmax) gsz = gmax;
+  if (gsz < 1) gsz = 1;
   if (ndir == 4)
-    GA_LAUNCH((sga_bwd_point<4>), dim3(px_grid(npix)), dim3(256), st, x, gx, pa, D, H, W, npix, accumulate);
+    GA_LAUNCH((sga_bwd_point<4>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix, accumulate);
   else
-    GA_LAUNCH((sga_bwd_point<1>), dim3(px_grid(npix)), dim3(256), st, x, gx, pa, D, H, W, npix, accumulate);
+    GA_LAUNCH((sga_bwd_point<1>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix, accumulate);
   return check_launch("sga per-pixel gradients");
 }
 
@@ -530,6 +538,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_MERGE4")) g_opt.merge4 = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_POINT_BLOCK")) g_opt.point_block = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);

@@ -154,3 +154,33 @@ def test_cpu_tensors_fail_loudly(torch_mod):
         SGA()(x, g, g, g, g)
     with pytest.raises(RuntimeError, match="no CPU path"):
         LGA2(2)(torch.randn(1, 3, 4, 4), torch.randn(1, 75, 4, 4))
+
+
+@pytest.mark.parametrize("offset", [4, 12, 20])
+def test_sga_on_16_byte_aligned_views(torch_mod, port_oracle, offset):
+    """Inputs that are only 16-byte aligned (views at an element offset into larger buffers): the row scans count
+    their batches from 128-byte line boundaries of the ADDRESS, so every misalignment is a different batch grid."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.functions.GANet import SgaFunction
+    torch.manual_seed(offset)
+    shape, gshape = (1, 2, 33, 6, 40), (1, 2, 5, 6, 40)
+
+    def view_of(t):
+        buf = torch.empty(t.numel() + 64, device="cuda")
+        v = buf[offset:offset + t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+
+    x = view_of(torch.randn(shape, device="cuda")).requires_grad_()
+    gs = [view_of(F.normalize(torch.randn(gshape, device="cuda"), p=1, dim=2)).requires_grad_() for _ in range(4)]
+    go = view_of(torch.randn(shape, device="cuda"))
+    assert x.data_ptr() % 128 != 0 and x.data_ptr() % 16 == 0
+    out = SgaFunction.apply(x, *gs)
+    grads = torch.autograd.grad(out, [x] + gs, go)
+    torch.cuda.synchronize()
+    o_out, o_tmp, o_mask = port_oracle.sga_forward(_np(x), *[_np(g) for g in gs])
+    o_g = port_oracle.sga_backward(_np(x), *[_np(g) for g in gs], o_tmp, o_mask, _np(go))
+    assert np.array_equal(_np(out), o_out)
+    for got, want in zip(grads, o_g):
+        assert np.abs(_np(got) - want).max() <= pc.TOL
