@@ -468,8 +468,8 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
     }
   }
   const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
-  if (transposed) GA_LAUNCH((lga_apply<R, true>), grid, dim3(256), st, x, f, y, geo);
-  else GA_LAUNCH((lga_apply<R, false>), grid, dim3(256), st, x, f, y, geo);
+  if (transposed) GA_LAUNCH((lga_apply<R, true>), grid, dim3(LGA_NT), st, x, f, y, geo);
+  else GA_LAUNCH((lga_apply<R, false>), grid, dim3(LGA_NT), st, x, f, y, geo);
   return check_launch("lga apply");
 }
 
@@ -479,8 +479,21 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
 {
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  if constexpr (LgaDCfg<R>::OK) {
+    if (opts().lga_wave == 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0 && (i64)H * W < (1ll << 31)) {
+      LgaSeg sg;
+      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+      sg.nseg = 1; sg.seg_len = D;
+      const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+      if (items < (1ll << 31)) {
+        GA_LAUNCH((lga_filter_grad_dma<R>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        return check_launch("lga filter grad (dma)");
+      }
+    }
+  }
   const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
-  GA_LAUNCH((lga_filter_grad<R>), grid, dim3(256), st, x, gy, gf, geo, acc);
+  GA_LAUNCH((lga_filter_grad<R>), grid, dim3(LGA_NT), st, x, gy, gf, geo, acc);
   return check_launch("lga filter grad");
 }
 

@@ -34,7 +34,11 @@
 namespace ga {
 
 constexpr int LGA_TW = 32;   // tile width  (pixels, = lanes along W)
-constexpr int LGA_TH = 8;    // tile height
+#ifndef GA_LGA_TH
+#define GA_LGA_TH 8
+#endif
+constexpr int LGA_TH = GA_LGA_TH;    // tile height
+constexpr int LGA_NT = LGA_TW * LGA_TH;   // threads per block of the tile kernels
 constexpr int LGA_PB = 4;    // planes per LDS stage
 #ifndef LGA_WAVES_PER_SIMD
 #define LGA_WAVES_PER_SIMD 3   // register cap for R <= 2: the march is latency-bound, occupancy pays
@@ -62,7 +66,7 @@ template <int R> struct LgaCfg {
   static constexpr int TH2 = LGA_TH + 2 * R;
   static constexpr int PLANE = TW2 * TH2;
   static constexpr int STAGE = PLANE * LGA_PB;
-  static constexpr int NLD = (STAGE + 255) / 256;    // staged elements per thread
+  static constexpr int NLD = (STAGE + LGA_NT - 1) / LGA_NT;    // staged elements per thread
 };
 
 struct LgaGeom {
@@ -88,7 +92,7 @@ GA_DEV void lga_stage_init(LgaStage<R> &st, const LgaGeom &geo, int ty0, int tx0
   typedef LgaCfg<R> C;
 #pragma unroll
   for (int l = 0; l < C::NLD; l++) {
-    const int e = l * 256 + (int)threadIdx.x;
+    const int e = l * LGA_NT + (int)threadIdx.x;
     st.off[l] = 0;
     st.msk[l] = 0u;
     st.pl[l] = 0;
@@ -120,7 +124,7 @@ GA_DEV void lga_stage_commit(float *__restrict__ buf, const LgaGeom &geo, const 
   typedef LgaCfg<R> C;
 #pragma unroll
   for (int l = 0; l < C::NLD; l++) {
-    const int e = l * 256 + (int)threadIdx.x;
+    const int e = l * LGA_NT + (int)threadIdx.x;
     const unsigned m = d0 + st.pl[l] < geo.D ? st.msk[l] : 0u;
     if (e < C::STAGE) reinterpret_cast<unsigned *>(buf)[e] = regs[l] & m;
   }
@@ -179,7 +183,7 @@ GA_DEV void lga_gather_weights(const float *__restrict__ fb, const LgaGeom &geo,
 // ---- forward (TRANSPOSED = false) and data-backward (TRANSPOSED = true) ---------
 // y[b,d,i,j] = sum_t w_t * xs(d+dd, i+a, j+b)  with centre replacement.
 template <int R, bool TRANSPOSED>
-__global__ void __launch_bounds__(256, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
+__global__ void __launch_bounds__(LGA_NT, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
           LgaGeom geo)
 {
@@ -784,10 +788,223 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
   GA_VMCNT(0);      // no DMA may still be in flight when the wave's LDS is handed to the next workgroup
 }
 
+// one 4-byte global -> LDS copy per lane: lane l's dword lands at slot + 4 * l
+GA_DEV void lga_dma4(const float *gsrc, float *slot, int lane)
+{
+#if defined(GA_HIPSIM)
+  slot[lane] = gsrc[0];
+#else
+  (void)lane;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
+}
+
+// ---- filter backward, wave-autonomous with LDS-DMA staging -----------------------------------
+// Same decomposition as lga_apply_dma (one wave = one 32 x 2 pixel tile, private plane ring, no
+// barrier, no staging registers), no depth segments (the 3K sums of a pixel run over all of D).  The
+// halo'd x plane arrives by one global_load_lds_dwordx4, the lane's own gy value by one
+// global_load_lds_dword into a second ring that runs one plane ahead (plane k pairs with gy[k-1],
+// gy[k], gy[k+1]).  Every vector-memory operation of the march is one of those two, issued in the
+// fixed order gy(k+1), x(k), so the in-order counter tells exactly what has landed: once x(j) is in,
+// so are gy(0..j+1), and after x(j) come two operations for each later plane.
+// The 256-thread tile kernel below spends its barriers and staging VALU on the same copies
+// (37 % of its wave time parked, profiles/r1m_pmc_summary.txt).
+#ifndef LGAF_NR
+#define LGAF_NR 8                // x-plane ring slots per wave (960 B each at R = 2; + 9 gy slots of 256 B: ~10 KB per wave)
+#endif
+template <int R>
+__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
+lga_filter_grad_dma(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
+                    LgaGeom geo, LgaSeg sg, int accumulate)
+{
+  typedef LgaCfg<R> C;
+  typedef LgaDCfg<R> DC;
+  static_assert(DC::OK, "one DMA instruction must cover a plane");
+  constexpr int NR = LGAF_NR, P = NR - 1, NG_ = NR + 1;
+  __shared__ __attribute__((aligned(16))) float ring[NR * DC::PLANE];
+  __shared__ __attribute__((aligned(16))) float gring[NG_ * 64];
+  const int lane = threadIdx.x;                       // blockDim.x == 64
+  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
+  int item = xcd_remap(blockIdx.x, gridDim.x);        // tiles along a row first; each XCD a contiguous band
+  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
+  const int by = item % sg.tiles_y;
+  const int b = item / sg.tiles_y;
+  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
+  const int i = ty0 + ty, j = tx0 + tx;
+  const bool inb = i < geo.H && j < geo.W;
+  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
+  const float *xb = x + (i64)b * geo.D * geo.HW;
+  const float *gyb = gy + (i64)b * geo.D * geo.HW;
+  float *gfb = gf + (i64)b * 3 * C::K * geo.HW;
+  const i64 pix = (i64)ic * geo.W + jc;
+  const int wcol = tx + DC::HALO - R;
+  const int par = wcol & 1;
+  const int rcol = wcol - par;
+  const int D = geo.D;
+
+  // clear the x ring (cells of out-of-image groups are never written again), then fill the pipeline
+#pragma unroll
+  for (int k = 0; k < (NR * DC::PLANE / 4 + 63) / 64; k++) {
+    const int e = k * 64 + lane;
+    if (e < NR * DC::PLANE / 4) *reinterpret_cast<f4 *>(ring + 4 * e) = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  GA_LGKMCNT0();
+  GA_WAVE_SYNC();
+  bool dma_on = false;
+  const float *gsrc = xb;
+  if (lane < DC::NG) {
+    const int r = lane / DC::G, c4 = lane - r * DC::G;
+    const int i2 = ty0 + r - R, j2 = tx0 - DC::HALO + 4 * c4;      // W % 4 == 0: a group is in or out as a whole
+    if (i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W) {
+      dma_on = true;
+      gsrc = xb + (i64)i2 * geo.W + j2;
+    }
+  }
+  const float *gysrc = gyb + pix;
+  int dma_slot = 0, g_slot = 0;
+  // x plane k (repeats the last plane past the end so that the operation count per step stays fixed)
+  auto dma_x = [&](int k) {
+    if (dma_on) lga_dma16(gsrc, ring + dma_slot * DC::PLANE, lane);
+    gsrc += k + 1 < D ? geo.HW : 0;
+    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
+  };
+  auto dma_g = [&](int k) {                            // gy plane k (clamped; its value is masked where k >= D)
+    lga_dma4(gysrc, gring + g_slot * 64, lane);
+    gysrc += k + 1 < D ? geo.HW : 0;
+    g_slot = g_slot + 1 == NG_ ? 0 : g_slot + 1;
+  };
+  dma_g(0);
+  for (int k = 0; k < P; k++) { dma_g(k + 1); dma_x(k); }
+
+  // partial sums per window slot: sab[a][k] = (slab -1, slab 0), sc[a][q] = slab +1 of (2q, 2q+1)
+  f2 sab[C::WS][C::NK], sc[C::WS][C::NP];
+#pragma unroll
+  for (int a = 0; a < C::WS; a++) {
+#pragma unroll
+    for (int k = 0; k < C::NK; k++) sab[a][k] = mk2(0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < C::NP; q++) sc[a][q] = mk2(0.f, 0.f);
+  }
+  float gc = 0.f;                 // sum_d gy[d] * x[d][centre]
+  float e_lo = 0.f, e_hi = 0.f;   // gy[0]*x[0][c], gy[D-1]*x[D-1][c]
+
+  constexpr int LA = LGAW_LA, U = LA + 1, NSTEP = U * C::WS;
+  static_assert(C::WS > LA, "look-ahead must stay within the next plane");
+  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + ty * DC::TW2 + rcol;
+  const lds_cptr gbase = GA_LDS_CPTR(&gring[0]) + lane;
+  f2 vrow[LA + 1][C::NP];
+  GA_VMCNT(2 * P - 2);                                     // x(0), gy(0), gy(1) have landed
+  GA_WAVE_SYNC();
+#pragma unroll
+  for (int s0 = 0; s0 < LA; s0++) {
+#pragma unroll
+    for (int q = 0; q < C::NP; q++) vrow[s0][q] = lds_read_b64(lbase + s0 * DC::TW2 + 2 * q);
+  }
+  float g_m = 0.f, g_0 = gbase[0];
+  int slot_c = 0;                                // ring slot of the x plane being visited
+  int gs_n = 1;                                  // gy ring slot of plane k + 1
+  for (int k0 = 0; k0 < D; k0 += U) {
+    float xc = 0.f, g_p = 0.f;
+    f2 g01 = mk2(0.f, 0.f), gmm = mk2(0.f, 0.f);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      const int u = st / C::WS, a = st % C::WS;
+      const int k = k0 + u;
+      const bool live = k < D;                               // uniform
+      if (a == 0) {
+        // the slots these overwrite held x(k-1) and gy(k-2), both consumed
+        dma_g(k + P + 1);
+        dma_x(k + P);
+        const float gv = gbase[gs_n * 64];                   // gy[k+1]: issued before x(k), which has landed (see below)
+        g_p = k + 1 < D ? gv : 0.f;
+        g01 = mk2(g_p, g_0);                                 // plane k pairs with gy[k+1] (slab -1), gy[k] (slab 0)
+        gmm = mk2(g_m, g_m);                                 // ... and gy[k-1] (slab +1)
+      }
+      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
+      const lds_cptr cur = lbase + slot_c * DC::PLANE, nxt = lbase + slot_n * DC::PLANE;
+      if (a == C::WS - LA) {
+        // x(k+1) -- and with it gy(k+2), issued just before it -- must have landed: after x(k+1) came
+        // two operations for each of the planes k+2 .. k+P
+        GA_VMCNT(2 * P - 2);
+        GA_WAVE_SYNC();
+      }
+      {
+        const int t = a + LA;
+        const lds_cptr src = t < C::WS ? cur + t * DC::TW2 : nxt + (t - C::WS) * DC::TW2;
+#pragma unroll
+        for (int q = 0; q < C::NP; q++) vrow[(st + LA) % (LA + 1)][q] = lds_read_b64(src + 2 * q);
+      }
+      GA_SCHED_FENCE();
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < C::NP; q++) {
+          const f2 vv = vrow[st % (LA + 1)][q];
+          sab[a][2 * q] = fma2(mk2(vv.x, vv.x), g01, sab[a][2 * q]);
+          sab[a][2 * q + 1] = fma2(mk2(vv.y, vv.y), g01, sab[a][2 * q + 1]);
+          sc[a][q] = fma2(vv, gmm, sc[a][q]);
+          if (a == R && 2 * q <= R && R <= 2 * q + 1) {
+            const float c0 = (R & 1) ? vv.y : vv.x;
+            xc = par ? xc : c0;
+          }
+          if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
+            const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
+            xc = par ? c1 : xc;
+          }
+        }
+      }
+      if (a == C::WS - 1) {
+        if (live) {
+          const float e = g_0 * xc;
+          gc += e;
+          if (k == 0) e_lo = e;
+          if (k == D - 1) e_hi = e;
+          g_m = g_0;
+          g_0 = g_p;
+        }
+        slot_c = slot_n;
+        gs_n = gs_n + 1 == NG_ ? 0 : gs_n + 1;
+      }
+    }
+  }
+  GA_VMCNT(0);      // no DMA may still be in flight when the wave's LDS is handed to the next workgroup
+
+  if (inb) {
+#pragma unroll
+    for (int dd = 0; dd < 3; dd++) {
+#pragma unroll
+      for (int a = -R; a <= R; a++) {
+#pragma unroll
+        for (int bb = -R; bb <= R; bb++) {
+          const int t = dd * C::K + (a + R) * C::WS + (bb + R);
+          const int i2 = i + a, j2 = j + bb;
+          const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
+          const int ke = bb + R, ko = bb + R + 1, ra = a + R;
+          float re, ro;
+          if (dd == 0) { re = sab[ra][ke].x; ro = sab[ra][ko].x; }
+          else if (dd == 1) { re = sab[ra][ke].y; ro = sab[ra][ko].y; }
+          else {
+            re = (ke & 1) ? sc[ra][ke >> 1].y : sc[ra][ke >> 1].x;
+            ro = (ko & 1) ? sc[ra][ko >> 1].y : sc[ra][ko >> 1].x;
+          }
+          float r = par ? ro : re;
+          if (dd == 0) r += e_lo;
+          if (dd == 2) r += e_hi;
+          if (!ok) r = gc;
+          float *dst = gfb + (i64)t * geo.HW + pix;
+          *dst = accumulate ? *dst + r : r;
+        }
+      }
+    }
+  }
+}
+
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)
 template <int R>
-__global__ void __launch_bounds__(256, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
+__global__ void __launch_bounds__(LGA_NT, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
                 LgaGeom geo, int accumulate)
 {
