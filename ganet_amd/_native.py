@@ -23,6 +23,7 @@ _PROTOS = {
     "ganet_set_option": [ctypes.c_char_p, _I],
     "ganet_sga_scan_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ganet_sga_forward": [_P] * 9 + [_I] * 5 + [_P],
+    "ganet_sga_forward_infer": [_P] * 9 + [_I] * 5 + [_P],
     "ganet_sga_backward_scan": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_sga_backward_dir": [_P] * 9 + [_I] * 7 + [_P],
     "ganet_sga_backward": [_P] * 15 + [_I] * 5 + [_P],

@@ -605,6 +605,30 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   return check_launch("sga merge");
 }
 
+GA_EXPORT int ganet_sga_forward_infer(const float *x, const float *g0, const float *g1, const float *g2,
+                                      const float *g3, float *A_ws, float *out, const float *bn_scale,
+                                      const float *bn_shift, int N, int C, int D, int H, int W,
+                                      void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out)
+    return fail(GANET_E_INVALID, "ganet_sga_forward_infer: null pointer");
+  if ((bn_scale == nullptr) != (bn_shift == nullptr))
+    return fail(GANET_E_INVALID, "ganet_sga_forward_infer: bn_scale and bn_shift go together");
+  GA_TRY(check_dims5("ganet_sga_forward_infer", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  const i64 slice = (i64)D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const float *gs[4] = {g0, g1, g2, g3};
+  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
+  if (slice % 4 == 0 && aligned16(A_ws) && aligned16(out))
+    GA_LAUNCH((sga_merge_infer<true>), dim3(ew_grid(n / 4)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n, A_ws + 3 * n,
+              out, bn_scale, bn_shift, C, slice, n);
+  else
+    GA_LAUNCH((sga_merge_infer<false>), dim3(ew_grid(n)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n, A_ws + 3 * n,
+              out, bn_scale, bn_shift, C, slice, n);
+  return check_launch("sga merge (inference)");
+}
+
 GA_EXPORT int ganet_sga_backward_scan(const float *g, const uint8_t *mask, const uint16_t *kp_dir,
                                       const float *grad_out, float *G, int N, int C, int D, int H,
                                       int W, int dir, void *stream)

@@ -702,6 +702,50 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
   }
 }
 
+// Inference-only merge: out = relu(scale[c] * max_dir A_dir + shift[c]) -- the direction max with the
+// eval-mode BatchNorm3d + ReLU that follow SGA in SGABlock.forward (models/GANet_deep.py:269-271) folded in;
+// no mask, no arg-max (nothing is kept for a backward).  scale == nullptr: plain max.  Elementwise, linear
+// order, 16-byte requests when n % 4 == 0 and the slice size is a multiple of 4.
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+sga_merge_infer(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
+                const float *__restrict__ A3, float *__restrict__ out, const float *__restrict__ scale,
+                const float *__restrict__ shift, int C, i64 slice /* D*H*W */, i64 n)
+{
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  if (VEC4) {
+    const i64 n4 = n >> 2;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const i64 e = i << 2;
+      const f4 a = *reinterpret_cast<const f4 *>(A0 + e), b = *reinterpret_cast<const f4 *>(A1 + e);
+      const f4 c_ = *reinterpret_cast<const f4 *>(A2 + e), d = *reinterpret_cast<const f4 *>(A3 + e);
+      float v[4] = {a.x, a.y, a.z, a.w};
+      const float w1[4] = {b.x, b.y, b.z, b.w}, w2[4] = {c_.x, c_.y, c_.z, c_.w}, w3[4] = {d.x, d.y, d.z, d.w};
+      float sc = 1.f, sh = 0.f;
+      if (scale) { const int ch = (int)((e / slice) % C); sc = scale[ch]; sh = shift[ch]; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (v[j] < w1[j]) v[j] = w1[j];
+        if (v[j] < w2[j]) v[j] = w2[j];
+        if (v[j] < w3[j]) v[j] = w3[j];
+        if (scale) v[j] = fmaxf(fmaf(v[j], sc, sh), 0.f);
+      }
+      f4 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; r.w = v[3];
+      *reinterpret_cast<f4 *>(out + e) = r;
+    }
+  } else {
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+      float v = A0[e];
+      const float b = A1[e], c_ = A2[e], d = A3[e];
+      if (v < b) v = b;
+      if (v < c_) v = c_;
+      if (v < d) v = d;
+      if (scale) { const int ch = (int)((e / slice) % C); v = fmaxf(fmaf(v, scale[ch], shift[ch]), 0.f); }
+      out[e] = v;
+    }
+  }
+}
+
 // first-argmax over d of one directional volume (reference-compatible path; MaxDepth :50-64)
 static __global__ void __launch_bounds__(256)
 sga_argmax_px(const float *__restrict__ A, uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)

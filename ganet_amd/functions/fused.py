@@ -13,7 +13,8 @@ from torch.autograd import Function
 from .. import _native
 from .GANet import _check, _p, _stream
 
-__all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters"]
+__all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
+           "sga_forward_infer"]
 
 
 def _lib():
@@ -100,3 +101,23 @@ class NormDisparityRegressionFunction(Function):
             _lib().call("ganet_norm_disparity_regression_backward", _p(x), _p(out), _p(snorm), _p(g), _p(gx),
                         N, D, H, W, _stream())
         return gx, None
+
+
+def sga_forward_infer(x, g0, g1, g2, g3, bn_scale=None, bn_shift=None):
+    """Inference-only SGA: relu(bn_scale[c] * SGA(x, g0..g3) + bn_shift[c]) in the merge kernel (plain SGA output when
+    bn_scale is None).  Nothing is saved for a backward: call it under torch.no_grad()
+    (SGABlock.forward, models/GANet_deep.py:269-271, in eval mode)."""
+    ts = [x, g0, g1, g2, g3] + ([bn_scale, bn_shift] if bn_scale is not None else [])
+    _check(*ts)
+    if any(t.requires_grad for t in ts) and torch.is_grad_enabled():
+        raise RuntimeError("sga_forward_infer keeps nothing for backward: wrap the call in torch.no_grad()")
+    N, C, D, H, W = x.shape
+    if bn_scale is not None and (bn_scale.numel() != C or bn_shift.numel() != C):
+        raise ValueError("bn_scale / bn_shift must have one entry per channel")
+    with torch.cuda.device_of(x):
+        A = torch.empty((4,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        out = torch.empty_like(x)
+        _lib().call("ganet_sga_forward_infer", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(A), _p(out),
+                    _p(bn_scale) if bn_scale is not None else None, _p(bn_shift) if bn_shift is not None else None,
+                    N, C, D, H, W, _stream())
+    return out

@@ -3,10 +3,11 @@ reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
 import torch
 from torch.nn.modules.module import Module
 
-from ..functions.fused import NormDisparityRegressionFunction, normalize_filters, normalize_guidance
+from ..functions.fused import (NormDisparityRegressionFunction, normalize_filters, normalize_guidance,
+                               sga_forward_infer)
 from ..functions.GANet import Lga2Function, SgaFunction
 
-__all__ = ["GuidedSGA", "NormalizedLGA2", "NormDisparityRegression", "DispAggTail"]
+__all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "DispAggTail"]
 
 
 class GuidedSGA(Module):
@@ -16,6 +17,29 @@ class GuidedSGA(Module):
     def forward(self, x, g):
         k1, k2, k3, k4 = normalize_guidance(g, x.shape[1])
         return SgaFunction.apply(x, k1, k2, k3, k4)
+
+
+class GuidedSGABnRelu(Module):
+    """SGABlock.forward lines models/GANet_deep.py:263-271 for refine=True blocks: normalise the guidance, SGA, then
+    `bn_relu` = BatchNorm3d + ReLU.  In eval mode without autograd the BatchNorm affine and the ReLU are applied inside
+    the direction-merge kernel (no mask / arg-max / saved volumes); otherwise the ops run one after the other."""
+
+    def __init__(self, bn):
+        super().__init__()
+        self.bn = bn                      # the block's torch.nn.BatchNorm3d (shared, not copied)
+
+    def forward(self, x, g):
+        ks = normalize_guidance(g, x.shape[1])
+        if self.training or torch.is_grad_enabled() or not self.bn.track_running_stats:
+            return torch.relu(self.bn(SgaFunction.apply(x, *ks)))
+        bn = self.bn
+        scale = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.affine:
+            scale = scale * bn.weight
+            shift = bn.bias - bn.running_mean * scale
+        else:
+            shift = -bn.running_mean * scale
+        return sga_forward_infer(x, *ks, scale.float().contiguous(), shift.float().contiguous())
 
 
 class NormalizedLGA2(Module):

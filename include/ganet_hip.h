@@ -60,6 +60,15 @@ int ganet_sga_forward(const float *x, const float *g0, const float *g1, const fl
                       const float *g3, float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
                       int N, int C, int D, int H, int W, void *stream);
 
+/* Inference-only forward: out = relu(bn_scale[c] * max_dir A_dir + bn_shift[c]) (bn_scale = bn_shift = NULL:
+ * plain max).  No mask / arg-max is produced and A_ws ([4][N*C*D*H*W]) is scratch.
+ * Replaces: sga_kernel_forward (GANet_kernel.cu:935-998) followed by the eval-mode BatchNorm3d + ReLU of
+ * SGABlock.forward (models/GANet_deep.py:269-271: `x = self.SGA(...); x = self.bn_relu(x)`), with
+ * bn_scale = weight / sqrt(running_var + eps), bn_shift = bias - running_mean * bn_scale. */
+int ganet_sga_forward_infer(const float *x, const float *g0, const float *g1, const float *g2,
+                            const float *g3, float *A_ws, float *out, const float *bn_scale,
+                            const float *bn_shift, int N, int C, int D, int H, int W, void *stream);
+
 /* Reverse-scan adjoint of one direction: G = [mask == dir] * grad_out propagated through the
  * recurrence with first-argmax routing (kp_dir: [N*C*H*W] uint16 of that direction).
  * Replaces: cudaMemset + get_temp_grad (:38-48) + the top_diff part of

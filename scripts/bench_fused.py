@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
-from ganet_amd.modules.fused import DispAggTail, GuidedSGA
+from ganet_amd.modules.fused import DispAggTail, GuidedSGA, GuidedSGABnRelu
 from ganet_amd.modules.GANet import SGA, LGA2, DisparityRegression
 
 dev = torch.device("cuda:0")
@@ -44,6 +44,26 @@ def fused_sgablock():
 
 res["sgablock_ref_ms"] = timed(ref_sgablock)
 res["sgablock_fused_ms"] = timed(fused_sgablock)
+
+# --- inference: normalise + SGA + BatchNorm3d(eval) + ReLU (models/GANet_deep.py:263-271), forward only
+bn = torch.nn.BatchNorm3d(32).to(dev).eval()
+fused_inf = GuidedSGABnRelu(bn).eval()
+
+
+def ref_infer():
+    with torch.no_grad():
+        k1, k2, k3, k4 = torch.split(g, (160, 160, 160, 160), 1)
+        ks = [F.normalize(k.view(1, 32, 5, 80, 208), p=1, dim=2) for k in (k1, k2, k3, k4)]
+        return torch.relu_(bn(sga(x, *ks)))
+
+
+def fused_infer():
+    with torch.no_grad():
+        return fused_inf(x, g)
+
+
+res["sgablock_infer_ref_ms"] = timed(ref_infer)
+res["sgablock_infer_fused_ms"] = timed(fused_infer)
 
 # --- DispAgg tail (models/GANet_deep.py:243-247), fwd+bwd
 xl = torch.randn(1, 193, 240, 624, device=dev, requires_grad=True)

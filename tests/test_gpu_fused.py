@@ -111,3 +111,34 @@ def test_norm_regression_full_size(torch_mod):
     ref.backward(go)
     np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-4)
     assert (x.grad - x2.grad).abs().max().item() <= 1e-3 * x2.grad.abs().max().item()
+
+
+def test_guided_sga_bn_relu_eval_matches_op_chain(torch_mod, port_oracle):
+    """GuidedSGABnRelu in eval mode / no_grad (BN affine + ReLU inside the merge kernel) == the op chain
+    normalise -> SGA -> BatchNorm3d(eval) -> ReLU of models/GANet_deep.py:263-271, and the training path still
+    differentiates."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import GuidedSGABnRelu
+    torch.manual_seed(11)
+    N, C, D, H, W = 1, 4, 33, 10, 24
+    bn = torch.nn.BatchNorm3d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    m = GuidedSGABnRelu(bn).eval()
+    x = torch.randn(N, C, D, H, W, device="cuda")
+    g = torch.randn(N, 20 * C, H, W, device="cuda")
+    with torch.no_grad():
+        got = m(x, g)
+    ks = [np.ascontiguousarray(_np(k)) for k in fr.sgablock_guidance(g.cpu(), C)]
+    o_out, _, _ = port_oracle.sga_forward(_np(x), *ks)
+    bn_cpu = torch.nn.BatchNorm3d(C).eval()
+    bn_cpu.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+    with torch.no_grad():
+        want = torch.relu(bn_cpu(torch.from_numpy(o_out)))
+    assert np.abs(_np(got) - want.numpy()).max() <= pc.TOL
+    # with autograd on, the same module runs the differentiable chain
+    x.requires_grad_(); g.requires_grad_()
+    y = m(x, g)
+    y.sum().backward()
+    assert x.grad is not None and g.grad is not None
+    assert np.abs(_np(y) - want.numpy()).max() <= pc.TOL

@@ -89,3 +89,25 @@ def test_argument_errors(sim):
         sim.call("ganet_l1_normalize_forward", _p(a), _p(a), _p(a), _p(a), _p(a), 1, 5, 1, 5, 2, 2, None)
     with pytest.raises(GanetError, match="null output 1"):
         sim.call("ganet_l1_normalize_forward", _p(a), _p(a), None, None, None, 1, 2, 1, 5, 2, 2, None)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 9, 4, 8), (2, 2, 5, 3, 5)])     # slice % 4 == 0 (16-byte path) and not
+@pytest.mark.parametrize("with_bn", [True, False])
+def test_sga_forward_infer_bn_relu_epilogue(sim, port_oracle, shape, with_bn):
+    """out = relu(scale[c] * SGA(x, g) + shift[c]) (models/GANet_deep.py:269-271 in eval mode) vs the C oracle + torch."""
+    import parity_cases as pc
+    x, gs, _ = pc.sga_inputs(shape, seed=sum(shape))
+    N, C, D, H, W = shape
+    rng = np.random.default_rng(3)
+    scale = rng.uniform(0.5, 2.0, C).astype(np.float32)
+    shift = rng.standard_normal(C).astype(np.float32)
+    A = np.empty((4,) + shape, np.float32)
+    out = np.full(shape, np.nan, np.float32)
+    sim.call("ganet_sga_forward_infer", _p(x), *[_p(g) for g in gs], _p(A), _p(out),
+             _p(scale) if with_bn else None, _p(shift) if with_bn else None, N, C, D, H, W, None)
+    want, _, _ = port_oracle.sga_forward(x, *gs)
+    if with_bn:
+        want = np.maximum(want * scale.reshape(1, C, 1, 1, 1) + shift.reshape(1, C, 1, 1, 1), 0).astype(np.float32)
+        np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)     # fma vs mul+add
+    else:
+        assert np.array_equal(out, want)
