@@ -260,3 +260,37 @@ def test_cost_volume_and_regression(api, dev, port_oracle):
     api.call("ganet_disparity_regression_forward", dev.to(p).data_ptr(), out.data_ptr(), N, 193, H, W, dev.stream)
     np.testing.assert_allclose(dev.host(out), port_oracle.disparity_regression(p, 192), rtol=1e-5, atol=1e-4)
     assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("shape", [(1, 193, 384, 1248), (2, 193, 528, 960), (1, 193, 241, 624)])
+def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
+    """The LGA shapes of BASELINE configs 3 and 5 (KITTI 1248x384; SceneFlow 960x528, 2 samples per GPU) and an odd
+    height: the wave-autonomous LDS-DMA kernels (default) and the 256-thread tile kernels (GANET_LGA_WAVE=0) are
+    different kernel families and must agree to fp32 rounding, forward, data gradient and filter gradient; the
+    bilinear identity <y, gy> == <x, gX> == <f, gF> holds for both -- no oracle in the loop."""
+    torch = dev.torch
+    B, D, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    xl = torch.randn(shape, device="cuda", generator=g)
+    f = torch.nn.functional.normalize(torch.randn((B, 75, H, W), device="cuda", generator=g), p=1, dim=1)
+    gy = torch.randn(shape, device="cuda", generator=g)
+    res = {}
+    try:
+        for mode in (2, 0):
+            api.set_option("GANET_LGA_WAVE", mode)
+            y, gx, gf = torch.empty_like(xl), torch.empty_like(xl), torch.empty_like(f)
+            api.call("ganet_lga_forward", xl.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, dev.stream)
+            api.call("ganet_lga_backward", xl.data_ptr(), f.data_ptr(), gy.data_ptr(), gx.data_ptr(), gf.data_ptr(),
+                     B, D, H, W, 2, 0, dev.stream)
+            torch.cuda.synchronize()
+            res[mode] = (y, gx, gf)
+    finally:
+        api.set_option("GANET_LGA_WAVE", 2)
+    for a, b in zip(res[2], res[0]):
+        assert (a - b).abs().max().item() <= 2e-5, (a - b).abs().max().item()
+    y, gx, gf = res[2]
+    a = (y.double() * gy.double()).sum().item()
+    b = (xl.double() * gx.double()).sum().item()
+    c = (f.double() * gf.double()).sum().item()
+    scale = (y.double().abs() * gy.double().abs()).sum().item()
+    assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
