@@ -75,6 +75,22 @@ def one_step(inp):
     return g1, g2
 
 
+def one_step_two_streams(inp, side):
+    """Same work as one_step, the SGA half on the current stream and the LGA half on `side`: the two halves of a
+    step have no data dependency in this workload (reported separately, never as `value`)."""
+    from ganet_amd.functions.GANet import Lga2Function, SgaFunction
+    x, gs, go, xl, f, gy = inp
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        y = Lga2Function.apply(xl, f, RADIUS)
+        g2 = torch.autograd.grad(y, [xl, f], gy)
+    out = SgaFunction.apply(x, *gs)
+    g1 = torch.autograd.grad(out, [x] + gs, go)
+    cur.wait_stream(side)
+    return g1, g2
+
+
 def stage_timings(inp, iters=5):
     """Per-stage device time (ms) with HIP events on the launch stream, via the C ABI."""
     from ganet_amd import _native
@@ -242,6 +258,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="also time the step with its SGA and LGA halves on two streams (extra field, not `value`)")
     args = ap.parse_args()
 
     ctx = gdist.init(args.gpus)
@@ -310,6 +328,30 @@ def main():
                 one_step(inp)
             torch.cuda.synchronize()
             line["eager_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+        if args.overlap:
+            # informational: SGA half and LGA half of the step on two streams (memory-bound scans beside VALU-bound LGA)
+            try:
+                side2 = torch.cuda.Stream()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    for _ in range(3):
+                        one_step_two_streams(inp, side2)
+                torch.cuda.current_stream().wait_stream(cap)
+                torch.cuda.synchronize()
+                g2s = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2s):
+                    keep2 = one_step_two_streams(inp, side2)
+                for _ in range(args.warmup):
+                    g2s.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    g2s.replay()
+                torch.cuda.synchronize()
+                line["two_stream_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+            except Exception as e:
+                line["two_stream_ms_per_step"] = f"failed: {type(e).__name__}: {e}"
         if not args.no_roofline:
             stages = stage_timings(inp)
             line["roofline"] = roofline_from_stages(stages)

@@ -187,7 +187,12 @@ int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_GD_V / GANET_SGA_GD_H = 4|8|16  lanes per scanline, vertical / horizontal scans
  *                         (defaults 4 / 16; GANET_SGA_GD sets both through ganet_set_option)
  *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
- *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans */
+ *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans (segment kernels)
+ *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: segment kernels)
+ *   GANET_SGA_MERGE4 = 0|1  four-pixels-per-lane merge + arg-max (default 1)
+ *   GANET_SGA_POINT_BLOCK = 64|128|256  threads per block of the per-pixel gradient kernel (default 256)
+ *   GANET_LGA_WAVE = 0|1|2  LGA kernels: 256-thread tiles | wave-autonomous, register staging | wave-autonomous, LDS-DMA (default 2)
+ *   GANET_LGA_SEGS = n      depth segments per tile for the wave-autonomous LGA kernels (0 = automatic) */
 int ganet_set_option(const char *name, int value);
 
 #ifdef __cplusplus
