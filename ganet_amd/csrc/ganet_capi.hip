@@ -404,10 +404,10 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
-  if (ndir == 4)
-    GA_LAUNCH((sga_bwd_point<4>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix, accumulate);
-  else
-    GA_LAUNCH((sga_bwd_point<1>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix, accumulate);
+  if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+  else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+  else if (accumulate) GA_LAUNCH((sga_bwd_point<1, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+  else GA_LAUNCH((sga_bwd_point<1, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   return check_launch("sga per-pixel gradients");
 }
 

@@ -155,8 +155,11 @@ GA_DEV void lga_gather_weights(const float *__restrict__ fb, const LgaGeom &geo,
         if (CHECK || !TRANSPOSED || dd != 1) own = fp[(i64)t * geo.HW];   // interior gX needs own taps only for the d-edge sums
         float wv = own;
         if (TRANSPOSED) {
+          // unconditional load (own pixel where the neighbour is outside the image, value dropped below): under a
+          // condition every one of the 75 loads of a border tile is followed by s_waitcnt vmcnt(0)
           const int tf = (2 - dd) * C::K + (-a + R) * C::WS + (-bb + R);
-          wv = ok ? fp[(i64)tf * geo.HW + a * geo.W + bb] : 0.f;
+          const int noff = ok ? a * geo.W + bb : 0;
+          wv = fp[(i64)tf * geo.HW + noff];
         }
         wt[dd][bb + R] = ok ? wv : 0.f;
         if (!ok) cmid += own;
@@ -974,6 +977,16 @@ lga_filter_grad_dma(const float *__restrict__ x, const float *__restrict__ gy, f
   if (inb) {
 #pragma unroll
     for (int dd = 0; dd < 3; dd++) {
+      // accumulate mode: the K old values of this depth slab are loaded together, then added and stored
+      // (written as `*dst = accumulate ? *dst + r : r` every tap is load -> s_waitcnt vmcnt(0) -> store:
+      // 75 serial round trips per lane, +30 us on the second pass of an LGA2 backward)
+      float old[C::K];
+#pragma unroll
+      for (int k = 0; k < C::K; k++) old[k] = 0.f;
+      if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < C::K; k++) old[k] = gfb[(i64)(dd * C::K + k) * geo.HW + pix];
+      }
 #pragma unroll
       for (int a = -R; a <= R; a++) {
 #pragma unroll
@@ -993,8 +1006,7 @@ lga_filter_grad_dma(const float *__restrict__ x, const float *__restrict__ gy, f
           if (dd == 0) r += e_lo;
           if (dd == 2) r += e_hi;
           if (!ok) r = gc;
-          float *dst = gfb + (i64)t * geo.HW + pix;
-          *dst = accumulate ? *dst + r : r;
+          gfb[(i64)t * geo.HW + pix] = old[(a + R) * C::WS + (bb + R)] + r;
         }
       }
     }
@@ -1116,6 +1128,16 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
   if (inb) {
 #pragma unroll
     for (int dd = 0; dd < 3; dd++) {
+      // accumulate mode: the K old values of this depth slab are loaded together, then added and stored
+      // (written as `*dst = accumulate ? *dst + r : r` every tap is load -> s_waitcnt vmcnt(0) -> store:
+      // 75 serial round trips per lane, +30 us on the second pass of an LGA2 backward)
+      float old[C::K];
+#pragma unroll
+      for (int k = 0; k < C::K; k++) old[k] = 0.f;
+      if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < C::K; k++) old[k] = gfb[(i64)(dd * C::K + k) * geo.HW + pix];
+      }
 #pragma unroll
       for (int a = -R; a <= R; a++) {
 #pragma unroll
@@ -1136,8 +1158,7 @@ lga_filter_grad(const float *__restrict__ x, const float *__restrict__ gy, float
           if (dd == 0) r += e_lo;
           if (dd == 2) r += e_hi;
           if (!ok) r = gc;
-          float *dst = gfb + (i64)t * geo.HW + pix;
-          *dst = accumulate ? *dst + r : r;
+          gfb[(i64)t * geo.HW + pix] = old[(a + R) * C::WS + (bb + R)] + r;
         }
       }
     }

@@ -46,10 +46,24 @@ cost_volume_bwd(const float *__restrict__ gcost, float *__restrict__ gx, float *
     const int n = (int)(r / C);
     const float *gl = gcost + (((i64)n * 2 * C + c) * Dn) * HW + (i64)h * W;
     const float *gr = gcost + (((i64)n * 2 * C + C + c) * Dn) * HW + (i64)h * W;
+    // unconditional loads (column clamped into the row, value masked) in groups of 8: a load under a condition is
+    // followed by s_waitcnt vmcnt(0), one memory round trip per disparity
     float sx = 0.f, sy = 0.f;
-    for (int i = 0; i < Dn; i++) {
-      if (i <= w) sx += gl[(i64)i * HW + w];
-      if (w + i < W) sy += gr[(i64)i * HW + w + i];
+    for (int i0 = 0; i0 < Dn; i0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u < Dn ? i0 + u : Dn - 1;
+        const int wr = w + i < W ? w + i : W - 1;
+        a[u] = gl[(i64)i * HW + w];
+        b[u] = gr[(i64)i * HW + wr];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u;
+        if (i < Dn && i <= w) sx += a[u];
+        if (i < Dn && w + i < W) sy += b[u];
+      }
     }
     gx[o] = sx;
     gy[o] = sy;
@@ -66,7 +80,14 @@ disp_regression_fwd(const float *__restrict__ x, float *__restrict__ out, int N,
     const i64 n = o / HW, pix = o - n * HW;
     const float *xp = x + n * Dn * HW + pix;
     float acc = 0.f;
-    for (int d = 0; d < Dn; d++) acc = fmaf(xp[(i64)d * HW], (float)d, acc);
+    for (int d0 = 0; d0 < Dn; d0 += 8) {       // 8 loads in flight per lane (same summation order)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) acc = fmaf(v[u], (float)(d0 + u), acc);
+    }
     out[o] = acc;
   }
 }
@@ -197,10 +218,13 @@ norm_disp_regression_fwd(const float *__restrict__ x, float *__restrict__ out, f
     const i64 n = o / HW, pix = o - n * HW;
     const float *xp = x + n * Dn * HW + pix;
     float acc = 0.f, sa = 0.f;
-    for (int d = 0; d < Dn; d++) {
-      const float v = xp[(i64)d * HW];
-      acc = fmaf(v, (float)d, acc);
-      sa += fabsf(v);
+    for (int d0 = 0; d0 < Dn; d0 += 8) {       // 8 loads in flight per lane
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) { acc = fmaf(v[u], (float)(d0 + u), acc); sa += fabsf(v[u]); }
     }
     const float sden = fmaxf(sa, GA_NORM_EPS);
     out[o] = acc / sden;

@@ -490,10 +490,10 @@ struct PointArgs {
 #ifndef GA_POINT_WAVES
 #define GA_POINT_WAVES 5
 #endif
-template <int NDIR>
+template <int NDIR, bool ACC>
 __global__ void __launch_bounds__(256, GA_POINT_WAVES)
 sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa,
-              int D, int H, int W, i64 npix, int accumulate)
+              int D, int H, int W, i64 npix)
 {
   // Register diet: this kernel is pure load->use latency (91 % of wave time in s_waitcnt), so
   // waves per SIMD is what counts.  Measured at cfg2: 127 VGPR / 4 waves 0.50 ms, 96 VGPR /
@@ -530,16 +530,20 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
     constexpr int DU = GA_POINT_DU;
     for (int dc = 0; dc < D; dc += DU) {
       float xv[DU], gxv[DU], Gv[DU][NDIR], Av[DU][NDIR];
+      // every load is unconditional (plane indices clamped into the volume, values masked afterwards): a load
+      // under a condition sits in a branch of its own and hipcc guards the next use of its register with
+      // s_waitcnt vmcnt(0) right behind it -- eight serialised memory round trips per step instead of one
 #pragma unroll
       for (int u = 0; u < DU; u++) {
         const int d = dc + u;
         const i64 o = vb + (i64)(d < D ? d : D - 1) * HW;
+        const i64 on = vb + (i64)(d + 1 < D ? d + 1 : D - 1) * HW;
         xv[u] = x[o];
-        gxv[u] = accumulate ? gradX[o] : 0.f;
+        gxv[u] = ACC ? gradX[o] : 0.f;
 #pragma unroll
         for (int q = 0; q < NDIR; q++) {
           Gv[u][q] = pa.G[q][o];
-          Av[u][q] = d + 1 < D ? pa.A[q][o + HW + poff[q]] : 0.f;   // A[pp][d+1]
+          Av[u][q] = pa.A[q][on + poff[q]];                          // A[pp][d+1] (used only where d + 1 < D)
         }
       }
 #pragma unroll

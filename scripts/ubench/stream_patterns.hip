@@ -76,6 +76,42 @@ __global__ void __launch_bounds__(256) k_march1(const float *a0, const float *a1
   }
 }
 
+// nine volumes in, one out, one pixel per lane marching over d (the shape of sga_bwd_point): a[4..7] are read at a
+// neighbouring pixel (-W, +W, -1, +1) like the forward volumes of the previous scan position
+template <int DU, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_march9(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
+                                                        const float *a0, const float *a1, const float *a2, const float *a3, float *o)
+{
+  const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (i64)S * HW) return;
+  const i64 s = p / HW, pix = p - s * HW, vb = s * D * HW + pix;
+  const int W = 208;
+  const int h = (int)(pix / W), w = (int)(pix % W);
+  const int o0 = h > 0 ? -W : 0, o1 = h < 79 ? W : 0, o2 = w > 0 ? -1 : 0, o3 = w < W - 1 ? 1 : 0;
+  float acc = 0.f;
+  for (int dc = 0; dc < D; dc += DU) {
+    float v[DU][9];
+#pragma unroll
+    for (int u = 0; u < DU; u++) {
+      const int d = dc + u < D ? dc + u : D - 1;
+      const i64 off = vb + (i64)d * HW;
+      v[u][0] = x[off]; v[u][1] = g0[off]; v[u][2] = g1[off]; v[u][3] = g2[off]; v[u][4] = g3[off];
+      v[u][5] = a0[off + o0]; v[u][6] = a1[off + o1]; v[u][7] = a2[off + o2]; v[u][8] = a3[off + o3];
+    }
+#pragma unroll
+    for (int u = 0; u < DU; u++) {
+      const int d = dc + u;
+      if (d < D) {
+        float r = v[u][0];
+#pragma unroll
+        for (int q = 1; q < 9; q++) r = fmaf(r, 0.5f, v[u][q]);
+        acc += r;
+        o[vb + (i64)d * HW] = r + acc;
+      }
+    }
+  }
+}
+
 template <typename F> void run(const char *name, F launch)
 {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -104,5 +140,13 @@ int main()
   run("march 1px DU=4", [&] { k_march1<4><<<(unsigned)(((i64)S * HW + 255) / 256), 256>>>(a[0], a[1], a[2], a[3], o); });
 #define M(PX4, DU, B) run("march4 PX4=" #PX4 " DU=" #DU " B=" #B, [&] { const i64 nq = (i64)S * HW / 4 / PX4; k_march<PX4, DU, B><<<(unsigned)((nq + B - 1) / B), B>>>(a[0], a[1], a[2], a[3], o); });
   M(1, 1, 64) M(1, 2, 64) M(1, 4, 64) M(1, 1, 256) M(1, 2, 256) M(1, 4, 256) M(2, 1, 64) M(2, 2, 64) M(5, 1, 64)
+  {
+    float *b[9];
+    for (int i = 0; i < 9; i++) { hipMalloc(&b[i], n * 4); hipMemset(b[i], i, n * 4); }
+    const unsigned grid = (unsigned)(((i64)S * HW + 255) / 256);
+    printf("nine in / one out (x2 for the byte count shown: multiply TB/s by 2)\n");
+#define M9(DU, WV) run("march9 1px DU=" #DU " waves=" #WV, [&] { k_march9<DU, WV><<<grid, 256>>>(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], o); });
+    M9(1, 8) M9(2, 8) M9(2, 5) M9(4, 4) M9(4, 8)
+  }
   return 0;
 }
