@@ -161,10 +161,12 @@ GA_DEV void lga_gather_weights(const float *__restrict__ fb, const LgaGeom &geo,
           const int noff = ok ? a * geo.W + bb : 0;
           wv = fp[(i64)tf * geo.HW + noff];
         }
-        wt[dd][bb + R] = ok ? wv : 0.f;
-        if (!ok) cmid += own;
-        else if (dd == 0) sin_m += own;
-        else if (dd == 2) sin_p += own;
+        // (masked with AND, not selected: a select lets the compiler sink the load back under the condition)
+        const int okm = ok ? -1 : 0;
+        wt[dd][bb + R] = i2f(f2i(wv) & okm);
+        cmid += i2f(f2i(own) & ~okm);
+        if (dd == 0) sin_m += i2f(f2i(own) & okm);
+        if (dd == 2) sin_p += i2f(f2i(own) & okm);
       }
     }
     float w6[3][C::NK];
