@@ -155,7 +155,7 @@ _FAMILY_KERNELS = {
     "sga_merge_argmax": [["sga_merge_px4"]],
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
                      ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
-    "sga_bwd_point": [["sga_bwd_point<4>"]],
+    "sga_bwd_point": [["sga_bwd_point<4, false>"]],
     "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_dma<2>", "lga_apply_dma<2, true>"]],
     "lga_apply (fwd pass)": [["lga_apply_dma<2, false>"]],
 }
