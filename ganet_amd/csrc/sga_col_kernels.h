@@ -231,9 +231,14 @@ sga_col_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       if (M16) {                                                                   \
         sm[it] = *reinterpret_cast<const uint4 *>(mp);                             \
       } else {                                                                     \
-        uint32_t q4[4] = {0u, 0u, 0u, 0u};                                         \
-        _Pragma("unroll") for (int e = 0; e < 4; e++)                              \
-          if (c0 + 4 * e < W) q4[e] = *reinterpret_cast<const uint32_t *>(mp + 4 * e); \
+        /* four dword loads, unconditional (columns past W re-read the block's first group and are masked): */ \
+        /* under a condition each would be followed by s_waitcnt vmcnt(0) */         \
+        uint32_t q4[4];                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                            \
+          const bool in = c0 + 4 * e < W;                                          \
+          const uint32_t v = *reinterpret_cast<const uint32_t *>(mp + (in ? 4 * e : 0)); \
+          q4[e] = v & (in ? ~0u : 0u);                                             \
+        }                                                                          \
         sm[it].x = q4[0]; sm[it].y = q4[1]; sm[it].z = q4[2]; sm[it].w = q4[3];   \
       }                                                                            \
     }                                                                              \

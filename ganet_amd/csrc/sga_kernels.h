@@ -760,9 +760,13 @@ sga_argmax_px(const float *__restrict__ A, uint16_t *__restrict__ kp, int D, i64
     const i64 vb = s * D * HW + pix;
     float m = A[vb];
     int k = 0;
-    for (int d = 1; d < D; d++) {
-      const float a = A[vb + (i64)d * HW];
-      if (m < a) { m = a; k = d; }
+    for (int d0 = 1; d0 < D; d0 += 8) {          // 8 loads in flight per lane
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = A[vb + (i64)(d0 + u < D ? d0 + u : D - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < D && m < a[u]) { m = a[u]; k = d0 + u; }
     }
     kp[pidx] = (uint16_t)k;
   }
