@@ -39,6 +39,8 @@ _PROTOS = {
     "ganet_l1_normalize_backward": [_P] * 6 + [_I] * 6 + [_P],
     "ganet_norm_disparity_regression_forward": [_P] * 3 + [_I] * 4 + [_P],
     "ganet_norm_disparity_regression_backward": [_P] * 5 + [_I] * 4 + [_P],
+    "ganet_softmin_forward": [_P] * 2 + [_I] * 4 + [_P],
+    "ganet_softmin_backward": [_P] * 3 + [_I] * 4 + [_P],
     "ganet_selftest_dpp": [_P, _P, _P],
 }
 EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])

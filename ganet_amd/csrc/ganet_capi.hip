@@ -889,6 +889,25 @@ GA_EXPORT int ganet_norm_disparity_regression_backward(const float *x, const flo
   return check_launch("normalised disparity regression backward");
 }
 
+GA_EXPORT int ganet_softmin_forward(const float *x, float *y, int N, int Dn, int H, int W, void *stream)
+{
+  if (!x || !y) return fail(GANET_E_INVALID, "ganet_softmin_forward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0) return fail(GANET_E_INVALID, "ganet_softmin_forward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(softmin_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, y, N, Dn, HW);
+  return check_launch("softmin forward");
+}
+
+GA_EXPORT int ganet_softmin_backward(const float *y, const float *grad_y, float *grad_x, int N, int Dn, int H,
+                                     int W, void *stream)
+{
+  if (!y || !grad_y || !grad_x) return fail(GANET_E_INVALID, "ganet_softmin_backward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0) return fail(GANET_E_INVALID, "ganet_softmin_backward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(softmin_bwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, y, grad_y, grad_x, N, Dn, HW);
+  return check_launch("softmin backward");
+}
+
 GA_EXPORT int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream)
 {
   if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp: null pointer");

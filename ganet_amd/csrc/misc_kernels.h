@@ -253,4 +253,79 @@ norm_disp_regression_bwd(const float *__restrict__ x, const float *__restrict__ 
   }
 }
 
+// y[n,d,h,w] = softmax_d(-x)  (nn.Softmin(dim=1), models/GANet_deep.py:244): one lane per pixel, two walks over its
+// column (running max + rescaled sum, then the normalised exponentials), 8 loads in flight.  Stock PyTorch runs a
+// negation kernel plus a strided softmax (0.24 ms at [1,193,240,624]).
+static __global__ void __launch_bounds__(256)
+softmin_fwd(const float *__restrict__ x, float *__restrict__ y, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / HW, pix = o - n * HW;
+    const float *xp = x + n * Dn * HW + pix;
+    float *yp = y + n * Dn * HW + pix;
+    float m = -INFINITY, ssum = 0.f;
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = -xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+      float mc = m;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) mc = fmaxf(mc, v[u]);
+      ssum *= expf(m - mc);                   // (exp(-inf) = 0 on the first chunk)
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) ssum += expf(v[u] - mc);
+      m = mc;
+    }
+    const float inv = 1.f / ssum;
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = -xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) yp[(i64)(d0 + u) * HW] = expf(v[u] - m) * inv;
+    }
+  }
+}
+
+// gx = -y * (gy - sum_d gy*y)
+static __global__ void __launch_bounds__(256)
+softmin_bwd(const float *__restrict__ y, const float *__restrict__ gy, float *__restrict__ gx, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / HW, pix = o - n * HW;
+    const float *yp = y + n * Dn * HW + pix, *gp = gy + n * Dn * HW + pix;
+    float *gxp = gx + n * Dn * HW + pix;
+    float dot = 0.f;
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const i64 off = (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW;
+        a[u] = yp[off]; b[u] = gp[off];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) dot = fmaf(a[u], b[u], dot);
+    }
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const i64 off = (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW;
+        a[u] = yp[off]; b[u] = gp[off];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) gxp[(i64)(d0 + u) * HW] = -a[u] * (b[u] - dot);
+    }
+  }
+}
+
 }  // namespace ga

@@ -14,7 +14,7 @@ from .. import _native
 from .GANet import _check, _p, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
-           "sga_forward_infer"]
+           "sga_forward_infer", "SoftminFunction"]
 
 
 def _lib():
@@ -121,3 +121,30 @@ def sga_forward_infer(x, g0, g1, g2, g3, bn_scale=None, bn_shift=None):
                     _p(bn_scale) if bn_scale is not None else None, _p(bn_shift) if bn_shift is not None else None,
                     N, C, D, H, W, _stream())
     return out
+
+
+class SoftminFunction(Function):
+    """nn.Softmin(dim=1) on [N,D,H,W] (models/GANet_deep.py:244) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check(x)
+        if x.dim() != 4:
+            raise ValueError("expected [N,D,H,W]")
+        N, D, H, W = x.shape
+        with torch.cuda.device_of(x):
+            y = torch.empty_like(x)
+            _lib().call("ganet_softmin_forward", _p(x), _p(y), N, D, H, W, _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        y, = ctx.saved_tensors
+        g = grad_y.contiguous()
+        _check(g)
+        N, D, H, W = y.shape
+        with torch.cuda.device_of(g):
+            gx = torch.empty_like(y)
+            _lib().call("ganet_softmin_backward", _p(y), _p(g), _p(gx), N, D, H, W, _stream())
+        return gx

@@ -3,8 +3,8 @@ reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
 import torch
 from torch.nn.modules.module import Module
 
-from ..functions.fused import (NormDisparityRegressionFunction, normalize_filters, normalize_guidance,
-                               sga_forward_infer)
+from ..functions.fused import (NormDisparityRegressionFunction, SoftminFunction, normalize_filters,
+                               normalize_guidance, sga_forward_infer)
 from ..functions.GANet import Lga2Function, SgaFunction
 
 __all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "DispAggTail"]
@@ -71,12 +71,11 @@ class DispAggTail(Module):
     def __init__(self, maxdisp=192, radius=2):
         super().__init__()
         self.lga = NormalizedLGA2(radius)
-        self.softmax = torch.nn.Softmin(dim=1)
         self.disparity = NormDisparityRegression(maxdisp)
 
     def forward(self, x, lg1, lg2):
         assert lg1.size() == lg2.size()
         x = self.lga(x, lg1)
-        x = self.softmax(x)
+        x = SoftminFunction.apply(x.contiguous())
         x = self.lga(x, lg2)
         return self.disparity(x)

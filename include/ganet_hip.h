@@ -175,6 +175,12 @@ int ganet_norm_disparity_regression_backward(const float *x, const float *out, c
                                              const float *grad_out, float *grad_x,
                                              int N, int Dn, int H, int W, void *stream);
 
+/* y = softmax over the Dn axis of -x, x [N,Dn,H,W]  (nn.Softmin(dim=1) between the two LGA calls of DispAgg.forward,
+ * models/GANet_deep.py:244); backward from y and grad_y. */
+int ganet_softmin_forward(const float *x, float *y, int N, int Dn, int H, int W, void *stream);
+int ganet_softmin_backward(const float *y, const float *grad_y, float *grad_x,
+                           int N, int Dn, int H, int W, void *stream);
+
 /* ---------------------------------------------------------------- diagnostics ---- */
 
 /* Runs a 64-lane probe of every DPP pattern the kernels rely on and compares with

@@ -111,3 +111,22 @@ def test_sga_forward_infer_bn_relu_epilogue(sim, port_oracle, shape, with_bn):
         np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)     # fma vs mul+add
     else:
         assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("N,D,H,W", [(1, 7, 3, 5), (2, 193, 2, 3), (1, 16, 4, 4)])
+def test_softmin_forward_backward(sim, N, D, H, W):
+    """nn.Softmin(dim=1) (models/GANet_deep.py:244) vs torch on the CPU, incl. large-magnitude inputs."""
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((N, D, H, W)) * 5).astype(np.float32)
+    x[0, :, 0, 0] *= 20.0                                   # spread of ~100: the running-max rescale matters
+    gy = rng.standard_normal((N, D, H, W)).astype(np.float32)
+    y = np.full_like(x, np.nan)
+    sim.call("ganet_softmin_forward", _p(x), _p(y), N, D, H, W, None)
+    tx = torch.from_numpy(x).requires_grad_()
+    want = torch.nn.functional.softmin(tx, dim=1)
+    np.testing.assert_allclose(y, want.detach().numpy(), rtol=2e-6, atol=1e-7)
+    want.backward(torch.from_numpy(gy))
+    gx = np.full_like(x, np.nan)
+    sim.call("ganet_softmin_backward", _p(want.detach().numpy().copy()), _p(gy), _p(gx), N, D, H, W, None)
+    # (gy_d - sum gy*y cancels where y ~ 1: the order of the 193-term dot product shows up at the 1e-6 level)
+    np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-5, atol=1e-5)
