@@ -127,6 +127,7 @@ def test_softmin_forward_backward(sim, N, D, H, W):
     np.testing.assert_allclose(y, want.detach().numpy(), rtol=2e-6, atol=1e-7)
     want.backward(torch.from_numpy(gy))
     gx = np.full_like(x, np.nan)
-    sim.call("ganet_softmin_backward", _p(want.detach().numpy().copy()), _p(gy), _p(gx), N, D, H, W, None)
+    y_ref = np.ascontiguousarray(want.detach().numpy())          # (kept alive across the call)
+    sim.call("ganet_softmin_backward", _p(y_ref), _p(gy), _p(gx), N, D, H, W, None)
     # (gy_d - sum gy*y cancels where y ~ 1: the order of the 193-term dot product shows up at the 1e-6 level)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-5, atol=1e-5)
