@@ -57,7 +57,11 @@ GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 #define GA_KEEP_F2(v) asm volatile("" : "+v"(v))
 #define GA_OPAQUE_S(v) asm volatile("" : "+s"(v))   // uniform value the optimiser may not reason about
 // nothing is scheduled across this point: used to pin a hand-chosen instruction interleaving
+#if defined(GA_NO_SCHED_FENCE)
+#define GA_SCHED_FENCE() ((void)0)
+#else
 #define GA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #endif
 // one 8-byte LDS read that stays a ds_read_b64 (256 B/clk/CU): left alone, the compiler fuses
 // neighbouring pairs into ds_read2_b64, which the LDS serves at half that rate
