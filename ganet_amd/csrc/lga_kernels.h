@@ -352,9 +352,40 @@ template <int R> struct LgaWCfg {
 };
 
 
+// Work items of the wave-autonomous kernels = tiles x depth segments.  Two forms:
+//  * split_a == 0: nseg equal segments of seg_len planes, segment fastest in the item order;
+//  * split_a  > 0: two UNEQUAL segments per tile, [0, split_a) and [split_a, D), and all the long ones come first in
+//    the item order.  With fewer tiles than wave slots (3 per SIMD) equal halves mean two dispatch rounds of which
+//    the second is half empty (4,800 items on 3,072 slots at 240x624: 2 x 98 plane-times); with split_a ~ tiles*D/slots
+//    the long items take one slot each for the whole kernel and the short ones share the remaining slots, a few each:
+//    every slot is busy for ~tiles*D/slots plane-times (151 at 240x624).  Measured: forward pass 0.108 -> 0.103 ms
+//    (the slot model overstates it: a SIMD's waves share one VALU); no gain for the data-backward, which keeps one
+//    segment.
 struct LgaSeg {
   int nseg, seg_len, tiles_x, tiles_y;
+  int split_a;
 };
+
+// item -> (tile bx, by, batch b, depth range); each XCD (block id % 8) gets a contiguous band of tiles
+GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, int &d_lo, int &d_hi)
+{
+  int item, seg;
+  if (sg.split_a > 0) {
+    const int ntile = (int)(gridDim.x >> 1);
+    seg = (int)blockIdx.x >= ntile ? 1 : 0;
+    item = xcd_remap((int)blockIdx.x - seg * ntile, ntile);
+    d_lo = seg ? sg.split_a : 0;
+    d_hi = seg ? D : sg.split_a;
+  } else {
+    item = xcd_remap(blockIdx.x, gridDim.x);        // segment fastest: the segments of a tile read the same filter lines
+    seg = item % sg.nseg; item /= sg.nseg;
+    d_lo = seg * sg.seg_len;
+    d_hi = d_lo + sg.seg_len < D ? d_lo + sg.seg_len : D;
+  }
+  bx = item % sg.tiles_x; item /= sg.tiles_x;
+  by = item % sg.tiles_y;
+  b = item / sg.tiles_y;
+}
 
 template <int R, bool TRANSPOSED>
 __global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
@@ -366,13 +397,8 @@ lga_apply_wave(const float *__restrict__ x, const float *__restrict__ f, float *
   __shared__ __attribute__((aligned(16))) float tile[2][WC::STAGE];
   const int lane = threadIdx.x;                       // blockDim.x == 64
   const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  // item order: segment fastest (the segments of a tile read the same filter lines: keep them on
-  // one XCD's L2), then tiles along a row; each XCD gets a contiguous band of items
-  int item = xcd_remap(blockIdx.x, gridDim.x);
-  const int seg = item % sg.nseg; item /= sg.nseg;
-  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
-  const int by = item % sg.tiles_y;
-  const int b = item / sg.tiles_y;
+  int bx, by, b, d_lo, d_hi;
+  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);
   const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
   const int i = ty0 + ty, j = tx0 + tx;
   const bool inb = i < geo.H && j < geo.W;
@@ -386,8 +412,6 @@ lga_apply_wave(const float *__restrict__ x, const float *__restrict__ f, float *
   const int rcol = wcol - par;
 
   // output planes [d_lo, d_hi) need input planes [d_lo - 1, d_hi]
-  const int d_lo = seg * sg.seg_len;
-  const int d_hi = d_lo + sg.seg_len < geo.D ? d_lo + sg.seg_len : geo.D;
   if (d_lo >= geo.D) return;
   const int v_lo = d_lo > 0 ? d_lo - 1 : 0;
   const int v_hi = d_hi < geo.D ? d_hi : geo.D - 1;    // inclusive
@@ -618,11 +642,8 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
   __shared__ __attribute__((aligned(16))) float ring[NR * DC::PLANE];
   const int lane = threadIdx.x;                       // blockDim.x == 64
   const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int item = xcd_remap(blockIdx.x, gridDim.x);        // segment fastest, see lga_apply_wave
-  const int seg = item % sg.nseg; item /= sg.nseg;
-  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
-  const int by = item % sg.tiles_y;
-  const int b = item / sg.tiles_y;
+  int bx, by, b, d_lo, d_hi;
+  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);
   const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
   const int i = ty0 + ty, j = tx0 + tx;
   const bool inb = i < geo.H && j < geo.W;
@@ -635,8 +656,6 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
   const int par = wcol & 1;
   const int rcol = wcol - par;
 
-  const int d_lo = seg * sg.seg_len;
-  const int d_hi = d_lo + sg.seg_len < geo.D ? d_lo + sg.seg_len : geo.D;
   if (d_lo >= geo.D) return;
   const int v_lo = d_lo > 0 ? d_lo - 1 : 0;
   const int v_hi = d_hi < geo.D ? d_hi : geo.D - 1;    // inclusive

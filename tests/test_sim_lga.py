@@ -100,3 +100,22 @@ def test_lga_unsupported_radius(sim):
     x = np.zeros((1, 2, 2, 2), np.float32)
     with pytest.raises(GanetError, match="radius"):
         sim.call("ganet_lga_forward", x.ctypes.data, x.ctypes.data, x.ctypes.data + 4, 1, 2, 2, 2, 4, None)
+
+
+@pytest.mark.parametrize("split", [1, 4, 8])
+def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split):
+    """Two unequal depth segments per tile ([0, split) and [split, D), all first segments dispatched first): the
+    forward and the data-backward must not depend on where the volume is cut."""
+    import parity_cases as pc
+    rng = np.random.default_rng(split)
+    shape = (2, 9, 6, 40)
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((2, 75, 6, 40)), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+    sim.set_option("GANET_LGA_SPLIT", split)
+    try:
+        pc.check_lga_chain(sim, pc.NumpyDev(), x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+    finally:
+        sim.set_option("GANET_LGA_SPLIT", 1)
