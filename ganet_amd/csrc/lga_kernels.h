@@ -80,7 +80,7 @@ struct LgaGeom {
 // unconditional: an always-valid address, the value ANDed with an all-ones / zero mask.  Written as
 // "inside ? load : 0", every load sits in a branch of its own and hipcc, unable to tell whether one
 // is still pending, guards the next use of the staging registers with s_waitcnt vmcnt(0) -- right
-// behind the prefetch it was meant to overlap (profiles/r1k_scan_instruction_mix.txt).
+// behind the prefetch it was meant to overlap (scripts/isa_lint.py finds the pattern).
 template <int R> struct LgaStage {
   int off[LgaCfg<R>::NLD];          // element offset from the chunk's first plane (0 if outside the image)
   unsigned msk[LgaCfg<R>::NLD];     // ~0u inside the image, 0 outside
@@ -322,7 +322,7 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
 
 // ---- wave-autonomous forward / data-backward -----------------------------------------
 // Same arithmetic as lga_apply, different decomposition.  What the counters said about the
-// 256-thread version (profiles/r1j_pmc_lga_apply.txt): 2,400 waves on 1,024 SIMDs leave every SIMD
+// 256-thread version (profiles/r1i_pmc_summary.txt, lga_apply<2, false>): 2,400 waves on 1,024 SIMDs leave every SIMD
 // with 2 or 3 waves and the kernel lasts as long as the 3-wave ones; the four waves of a block sit
 // on four differently loaded SIMDs and meet at a barrier every chunk, so all of them run at the
 // pace of the slowest (37 % of wave time parked).  Here one WAVE owns a 32 x 2 pixel tile and a
@@ -431,7 +431,7 @@ lga_apply_wave(const float *__restrict__ x, const float *__restrict__ f, float *
   // to 64 * NLP cells).  A "valid ? load : 0" select is turned back into a branch per load by the
   // compiler, and the zero-initialised destination registers then cost an s_waitcnt vmcnt(0) in
   // front of every load group -- four serialised HBM round trips per chunk (61 % of wave time
-  // parked, profiles/r1j_pmc_lga_apply.txt).
+  // parked in the first version of this kernel).
   int off[WC::NLP];
   unsigned msk[WC::NLP];
 #pragma unroll
@@ -587,7 +587,7 @@ lga_apply_wave(const float *__restrict__ x, const float *__restrict__ f, float *
 
 // ---- wave-autonomous forward / data-backward, LDS-DMA staging -------------------------
 // The register-staged wave kernel above still loses ~25 % of its time waiting for the staging
-// loads (ablation, profiles/r1j_lga_ablation.txt): one chunk of look-ahead is all its registers
+// loads (ablation of this family: profiles/r1q_lga_ablation.txt): one chunk of look-ahead is all its registers
 // can hold.  Here the halo'd plane (6 rows x 40 floats = 60 16-byte groups at R = 2) is copied
 // global -> LDS by ONE global_load_lds_dwordx4 per plane, into a ring of LGAD_NR plane slots
 // private to the wave, LGAD_NR - 1 planes ahead of the arithmetic: no staging registers, no

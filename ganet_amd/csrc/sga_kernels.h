@@ -90,7 +90,7 @@ template <int GD, int DPL> GA_DEV LaneCtx make_ctx(const ScanGeom &geo)
 // FULL: the caller guarantees D % DPL == 0 (e.g. 65 = 13 x 5), so every lane lies wholly inside or
 // wholly outside [0, D) and the per-element range tests collapse to two per-lane selects.  A wave
 // issues about one instruction per 4-8 clk whatever it is, so a position costs what its instruction
-// count says (74 per position before this, profiles/r1k_scan_instruction_mix.txt).
+// count says (74 per position before this; static mix of the current kernels: profiles/r1q_instruction_mix.txt).
 template <int GD, int DPL, bool FULL = false>
 GA_DEV void fwd_step(const float (&xs)[DPL], const float (&w)[5], float (&A)[DPL], float &m,
                      bool first, const LaneCtx &c, int D)

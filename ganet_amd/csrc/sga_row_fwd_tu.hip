@@ -2,7 +2,7 @@
 // Reason: compiler flags.  With hipcc's SLP vectoriser on, neighbouring scalar FMAs of the recurrence
 // are packed into v_pk_fma_f32 and paid for with v_mov shuffles (12 per scan position here, the scan
 // 0.098 -> 0.082 ms without it); the vertical and adjoint scans in ganet_capi.hip are a few per cent
-// faster WITH it (profiles/r1k_scan_instruction_mix.txt).  build.py compiles this file with
+// faster WITH it (instruction mix of the current kernels: profiles/r1q_instruction_mix.txt).  build.py compiles this file with
 // -fno-slp-vectorize and links both objects into libganet_hip.so.
 #include "ga_launch.h"
 

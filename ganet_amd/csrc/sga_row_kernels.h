@@ -101,7 +101,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   // batch is computed and committed to LDS after it, so one HBM round trip overlaps 32 positions
   // of recurrence instead of preceding them (written the obvious way -- load, ds_write, next piece
   // -- hipcc emits load / s_waitcnt vmcnt(0) / ds_write per piece: nine serial round trips per
-  // batch, profiles/r1k_scan_instruction_mix.txt).  Loads are unconditional (addresses clamped
+  // batch; scripts/isa_lint.py counts such patterns).  Loads are unconditional (addresses clamped
   // into the row, the clamped copies are never committed): a conditional load makes the compiler
   // guard every later use of its registers with vmcnt(0).
   constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;      // pieces per lane and image row
