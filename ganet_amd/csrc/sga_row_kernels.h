@@ -28,9 +28,6 @@
 
 namespace ga {
 
-#ifndef SGA_ABLATE
-#define SGA_ABLATE 0     // development only: bit 0 no tile loads after the first batch, bit 1 no result stores
-#endif
 
 #ifndef GA_ROW_ALIGN
 #define GA_ROW_ALIGN 1   // 0: batches counted from the row start (A/B only)
