@@ -161,6 +161,11 @@ _FAMILY_KERNELS = {
 }
 
 
+FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
+_LGA_PASS_FLOPS = 2.0 * 75 * 193 * 240 * 624      # 75 FMAs per output element, one apply or one filter-gradient pass
+_FAMILY_FLOPS = {"lga_apply (fwd pass)": _LGA_PASS_FLOPS, "lga_apply+filter_grad (bwd pass)": 2 * _LGA_PASS_FLOPS}
+
+
 def pmc_traffic():
     """Per-kernel traffic (bytes per dispatch at the L2 <-> fabric boundary) from the committed rocprofv3 --pmc
     passes (profiles/traffic_pmc.json, made by scripts/gpu_pmc2.sh + scripts/pmc_traffic.py on an MI355X with
@@ -211,6 +216,12 @@ def roofline_from_stages(stages):
         row = {"kernel": name, "launches_per_step": len(keys) * mult, "avg_launch_ms": round(avg_ms, 4),
                "alg_bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 1),
                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _family_traffic(name, kern)}
+        if name in _FAMILY_FLOPS:
+            # LGA is the one family whose arithmetic bound (fp32 VALU = fp32 MFMA rate, 157.3 TFLOP/s) lies above its
+            # HBM bound (27.6 flop/B): report it against that peak as well
+            tf = _FAMILY_FLOPS[name] / (avg_ms * 1e-3) / 1e12
+            row["fp32_tflops"] = round(tf, 1)
+            row["fp32_frac"] = round(tf / FP32_PEAK_TFLOPS, 4)
         table.append(row)
         if step_ms > best_t:
             best, best_t = row, step_ms
