@@ -806,7 +806,10 @@ GA_EXPORT int ganet_cost_volume_forward(const float *x, const float *y, float *c
   if (N <= 0 || C <= 0 || Dn <= 0 || H <= 0 || W <= 0)
     return fail(GANET_E_INVALID, "ganet_cost_volume_forward: non-positive size");
   const i64 n = (i64)N * 2 * C * Dn * H * W;
-  GA_LAUNCH(cost_volume_fwd, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, x, y, cost, N, C, Dn, H, W);
+  if (W % 4 == 0 && aligned16(x) && aligned16(cost))
+    GA_LAUNCH(cost_volume_fwd4, dim3(ew_grid(n / 4)), dim3(256), (hipStream_t)stream, x, y, cost, N, C, Dn, H, W);
+  else
+    GA_LAUNCH(cost_volume_fwd, dim3(ew_grid(n)), dim3(256), (hipStream_t)stream, x, y, cost, N, C, Dn, H, W);
   return check_launch("cost volume forward");
 }
 
@@ -841,7 +844,10 @@ GA_EXPORT int ganet_disparity_regression_backward(const float *grad_out, float *
   if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
     return fail(GANET_E_INVALID, "ganet_disparity_regression_backward: non-positive size");
   const i64 HW = (i64)H * W;
-  GA_LAUNCH(disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, grad_out, grad_x, N, Dn, HW);
+  if (HW % 4 == 0 && aligned16(grad_out) && aligned16(grad_x))
+    GA_LAUNCH(disp_regression_bwd4, dim3(ew_grid((i64)N * (HW / 4))), dim3(256), (hipStream_t)stream, grad_out, grad_x, N, Dn, HW);
+  else
+    GA_LAUNCH(disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, grad_out, grad_x, N, Dn, HW);
   return check_launch("disparity regression backward");
 }
 

@@ -30,6 +30,44 @@ cost_volume_fwd(const float *__restrict__ x, const float *__restrict__ y, float 
   }
 }
 
+// the same with four consecutive columns per lane (W % 4 == 0, 16-byte aligned buffers): one index decomposition per
+// 16-byte store instead of per element (0.23 -> 0.06 ms at [1,64,65,80,208]); the shifted right-image samples are four
+// scalar loads (they hit L1/L2: the 2*C source planes are read Dn times)
+static __global__ void __launch_bounds__(256)
+cost_volume_fwd4(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ cost,
+                 int N, int C, int Dn, int H, int W)
+{
+  const int W4 = W >> 2;
+  const i64 total = (i64)N * 2 * C * Dn * H * W4;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const int w = (int)(q % W4) << 2;
+    i64 r = q / W4;
+    const int h = (int)(r % H); r /= H;
+    const int i = (int)(r % Dn); r /= Dn;
+    const int c = (int)(r % (2 * C));
+    const int n = (int)(r / (2 * C));
+    f4 v;
+    if (c < C) {
+      v = *reinterpret_cast<const f4 *>(x + (((i64)n * C + c) * H + h) * W + w);
+      if (w < i) v.x = 0.f;
+      if (w + 1 < i) v.y = 0.f;
+      if (w + 2 < i) v.z = 0.f;
+      if (w + 3 < i) v.w = 0.f;
+    } else {
+      const float *yr = y + (((i64)n * C + (c - C)) * H + h) * W;
+      const int s0 = w - i;                        // source column of the first element (may be negative)
+      const float a0 = yr[s0 > 0 ? s0 : 0], a1 = yr[s0 + 1 > 0 ? s0 + 1 : 0];
+      const float a2 = yr[s0 + 2 > 0 ? s0 + 2 : 0], a3 = yr[s0 + 3 > 0 ? s0 + 3 : 0];
+      v.x = s0 >= 0 ? a0 : 0.f;
+      v.y = s0 + 1 >= 0 ? a1 : 0.f;
+      v.z = s0 + 2 >= 0 ? a2 : 0.f;
+      v.w = s0 + 3 >= 0 ? a3 : 0.f;
+    }
+    *reinterpret_cast<f4 *>(cost + (q << 2)) = v;
+  }
+}
+
 // adjoint: gx[n,c,h,w] = sum_{i<=w} g[n,c,i,h,w];  gy[n,c,h,w] = sum_{i: w+i<W} g[n,C+c,i,h,w+i]
 __global__ void __launch_bounds__(256)
 cost_volume_bwd(const float *__restrict__ gcost, float *__restrict__ gx, float *__restrict__ gy,
@@ -104,6 +142,26 @@ disp_regression_bwd(const float *__restrict__ gout, float *__restrict__ gx, int 
     const int d = (int)(r % Dn);
     const i64 n = r / Dn;
     gx[o] = gout[n * HW + pix] * (float)d;
+  }
+}
+
+// the same with four pixels per lane marching over d (HW % 4 == 0, 16-byte aligned buffers): gout is read once,
+// every store is 16 bytes and no index is divided per element (0.10 -> 0.03 ms at [1,193,240,624])
+static __global__ void __launch_bounds__(256)
+disp_regression_bwd4(const float *__restrict__ gout, float *__restrict__ gx, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * (HW >> 2);
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const i64 n = q / (HW >> 2), pix = (q - n * (HW >> 2)) << 2;
+    const f4 g = *reinterpret_cast<const f4 *>(gout + n * HW + pix);
+    float *gp = gx + n * Dn * HW + pix;
+    for (int d = 0; d < Dn; d++) {
+      const float df = (float)d;
+      f4 r;
+      r.x = g.x * df; r.y = g.y * df; r.z = g.z * df; r.w = g.w * df;
+      *reinterpret_cast<f4 *>(gp + (i64)d * HW) = r;
+    }
   }
 }
 

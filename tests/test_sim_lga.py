@@ -68,9 +68,10 @@ def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
-def test_cost_volume_and_regression(sim, port_oracle):
+@pytest.mark.parametrize("W", [11, 12, 8])      # scalar kernels (W % 4 != 0) and the four-columns-per-lane ones
+def test_cost_volume_and_regression(sim, port_oracle, W):
     rng = np.random.default_rng(5)
-    N, C, H, W, maxdisp = 2, 3, 4, 11, 6
+    N, C, H, maxdisp = 2, 3, 4, 6
     Dn = maxdisp + 1
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
     y = rng.standard_normal((N, C, H, W)).astype(np.float32)
