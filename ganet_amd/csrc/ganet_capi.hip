@@ -925,8 +925,12 @@ GA_EXPORT int ganet_norm_disparity_regression_backward(const float *x, const flo
   if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
     return fail(GANET_E_INVALID, "ganet_norm_disparity_regression_backward: non-positive size");
   const i64 HW = (i64)H * W;
-  GA_LAUNCH(norm_disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, x, out, snorm,
-            grad_out, grad_x, N, Dn, HW);
+  if (HW % 4 == 0 && aligned16(x) && aligned16(out) && aligned16(snorm) && aligned16(grad_out) && aligned16(grad_x))
+    GA_LAUNCH(norm_disp_regression_bwd4, dim3(ew_grid((i64)N * (HW / 4))), dim3(256), (hipStream_t)stream, x, out, snorm,
+              grad_out, grad_x, N, Dn, HW);
+  else
+    GA_LAUNCH(norm_disp_regression_bwd, dim3(ew_grid((i64)N * Dn * HW)), dim3(256), (hipStream_t)stream, x, out, snorm,
+              grad_out, grad_x, N, Dn, HW);
   return check_launch("normalised disparity regression backward");
 }
 

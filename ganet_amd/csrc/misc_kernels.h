@@ -311,6 +311,49 @@ norm_disp_regression_bwd(const float *__restrict__ x, const float *__restrict__ 
   }
 }
 
+// the same, four pixels per lane marching over d (HW % 4 == 0, 16-byte aligned buffers), 4 planes in flight
+static __global__ void __launch_bounds__(256)
+norm_disp_regression_bwd4(const float *__restrict__ x, const float *__restrict__ out,
+                          const float *__restrict__ snorm, const float *__restrict__ gout,
+                          float *__restrict__ gx, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * (HW >> 2);
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const i64 n = q / (HW >> 2), pix = (q - n * (HW >> 2)) << 2;
+    const f4 so = *reinterpret_cast<const f4 *>(snorm + n * HW + pix);
+    const f4 oo = *reinterpret_cast<const f4 *>(out + n * HW + pix);
+    const f4 go = *reinterpret_cast<const f4 *>(gout + n * HW + pix);
+    const float sd[4] = {so.x, so.y, so.z, so.w}, gg[4] = {go.x, go.y, go.z, go.w};
+    float ov[4] = {oo.x, oo.y, oo.z, oo.w};
+    float gs[4];                                  // gout / s: one division per pixel, not per element
+#pragma unroll
+    for (int j = 0; j < 4; j++) { ov[j] = sd[j] > GA_NORM_EPS ? ov[j] : 0.f; gs[j] = gg[j] / sd[j]; }
+    const float *xp = x + n * Dn * HW + pix;
+    float *gp = gx + n * Dn * HW + pix;
+    for (int d0 = 0; d0 < Dn; d0 += 4) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f4 *>(xp + (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (d0 + u < Dn) {
+          const float df = (float)(d0 + u);
+          const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float sg = xv[j] > 0.f ? 1.f : (xv[j] < 0.f ? -1.f : 0.f);
+            r[j] = gs[j] * (df - ov[j] * sg);
+          }
+          f4 o_; o_.x = r[0]; o_.y = r[1]; o_.z = r[2]; o_.w = r[3];
+          *reinterpret_cast<f4 *>(gp + (i64)(d0 + u) * HW) = o_;
+        }
+      }
+    }
+  }
+}
+
 // y[n,d,h,w] = softmax_d(-x)  (nn.Softmin(dim=1), models/GANet_deep.py:244): one lane per pixel, two walks over its
 // column (running max + rescaled sum, then the normalised exponentials), 8 loads in flight.  Stock PyTorch runs a
 // negation kernel plus a strided softmax (0.24 ms at [1,193,240,624]).
