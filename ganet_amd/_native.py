@@ -41,6 +41,8 @@ _PROTOS = {
     "ganet_norm_disparity_regression_backward": [_P] * 5 + [_I] * 4 + [_P],
     "ganet_softmin_forward": [_P] * 2 + [_I] * 4 + [_P],
     "ganet_softmin_backward": [_P] * 3 + [_I] * 4 + [_P],
+    "ganet_softmin_regression_forward": [_P] * 4 + [_I] * 4 + [_P],
+    "ganet_softmin_regression_backward": [_P] * 6 + [_I] * 4 + [_P],
     "ganet_selftest_dpp": [_P, _P, _P],
 }
 EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])

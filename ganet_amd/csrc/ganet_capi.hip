@@ -953,6 +953,31 @@ GA_EXPORT int ganet_softmin_backward(const float *y, const float *grad_y, float 
   return check_launch("softmin backward");
 }
 
+GA_EXPORT int ganet_softmin_regression_forward(const float *x, float *out, float *mx, float *ssum, int N, int Dn,
+                                               int H, int W, void *stream)
+{
+  if (!x || !out || !mx || !ssum) return fail(GANET_E_INVALID, "ganet_softmin_regression_forward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_softmin_regression_forward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(softmin_regression_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, out, mx, ssum, N, Dn, HW);
+  return check_launch("softmin regression forward");
+}
+
+GA_EXPORT int ganet_softmin_regression_backward(const float *x, const float *out, const float *mx,
+                                                const float *ssum, const float *grad_out, float *grad_x,
+                                                int N, int Dn, int H, int W, void *stream)
+{
+  if (!x || !out || !mx || !ssum || !grad_out || !grad_x)
+    return fail(GANET_E_INVALID, "ganet_softmin_regression_backward: null pointer");
+  if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "ganet_softmin_regression_backward: non-positive size");
+  const i64 HW = (i64)H * W;
+  GA_LAUNCH(softmin_regression_bwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, out, mx, ssum,
+            grad_out, grad_x, N, Dn, HW);
+  return check_launch("softmin regression backward");
+}
+
 GA_EXPORT int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream)
 {
   if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp: null pointer");

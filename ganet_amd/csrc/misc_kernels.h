@@ -429,4 +429,63 @@ softmin_bwd(const float *__restrict__ y, const float *__restrict__ gy, float *__
   }
 }
 
+// out[n,h,w] = sum_d d * softmin_d(x)  (Disp.forward, models/GANet_deep.py:217-219: Softmin(dim=1) + DisparityRegression)
+// in ONE walk over the lane's column: running max m of -x with rescaled sums s = sum e^(-x-m), t = sum d e^(-x-m);
+// the probabilities are never written.  mx / ssum ([N,H,W]) are kept for the backward, which recomputes them:
+// gx_d = -gout * p_d * (d - out),  p_d = e^(-x_d - m) / s.
+static __global__ void __launch_bounds__(256)
+softmin_regression_fwd(const float *__restrict__ x, float *__restrict__ out, float *__restrict__ mx,
+                       float *__restrict__ ssum, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / HW, pix = o - n * HW;
+    const float *xp = x + n * Dn * HW + pix;
+    float m = -INFINITY, s_ = 0.f, t_ = 0.f;
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = -xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+      float mc = m;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) mc = fmaxf(mc, v[u]);
+      const float resc = expf(m - mc);
+      s_ *= resc; t_ *= resc;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) { const float e = expf(v[u] - mc); s_ += e; t_ = fmaf(e, (float)(d0 + u), t_); }
+      m = mc;
+    }
+    out[o] = t_ / s_;
+    mx[o] = m;
+    ssum[o] = s_;
+  }
+}
+
+static __global__ void __launch_bounds__(256)
+softmin_regression_bwd(const float *__restrict__ x, const float *__restrict__ out, const float *__restrict__ mx,
+                       const float *__restrict__ ssum, const float *__restrict__ gout, float *__restrict__ gx,
+                       int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * HW;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / HW, pix = o - n * HW;
+    const float *xp = x + n * Dn * HW + pix;
+    float *gp = gx + n * Dn * HW + pix;
+    const float m = mx[o], ov = out[o];
+    const float gs = -gout[o] / ssum[o];
+    for (int d0 = 0; d0 < Dn; d0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = -xp[(i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (d0 + u < Dn) gp[(i64)(d0 + u) * HW] = gs * expf(v[u] - m) * ((float)(d0 + u) - ov);
+    }
+  }
+}
+
 }  // namespace ga

@@ -14,7 +14,7 @@ from .. import _native
 from .GANet import _check, _p, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
-           "sga_forward_infer", "SoftminFunction"]
+           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction"]
 
 
 def _lib():
@@ -148,3 +148,33 @@ class SoftminFunction(Function):
             gx = torch.empty_like(y)
             _lib().call("ganet_softmin_backward", _p(y), _p(g), _p(gx), N, D, H, W, _stream())
         return gx
+
+
+class SoftminDisparityRegressionFunction(Function):
+    """out[N,H,W] = sum_d d * softmin_d(x): Disp.forward's Softmin(dim=1) + DisparityRegression
+    (models/GANet_deep.py:217-219) in one pass; the probabilities are never materialised."""
+
+    @staticmethod
+    def forward(ctx, x, ndisp):
+        _check(x)
+        if x.dim() != 4 or x.shape[1] != ndisp:
+            raise ValueError(f"expected [N,{ndisp},H,W], got {tuple(x.shape)}")
+        N, D, H, W = x.shape
+        with torch.cuda.device_of(x):
+            out = torch.empty((N, H, W), dtype=x.dtype, device=x.device)
+            mx, ssum = torch.empty_like(out), torch.empty_like(out)
+            _lib().call("ganet_softmin_regression_forward", _p(x), _p(out), _p(mx), _p(ssum), N, D, H, W, _stream())
+        ctx.save_for_backward(x, out, mx, ssum)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, out, mx, ssum = ctx.saved_tensors
+        g = grad_out.contiguous()
+        _check(g)
+        N, D, H, W = x.shape
+        with torch.cuda.device_of(g):
+            gx = torch.empty_like(x)
+            _lib().call("ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ssum), _p(g), _p(gx),
+                        N, D, H, W, _stream())
+        return gx, None

@@ -3,11 +3,12 @@ reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
 import torch
 from torch.nn.modules.module import Module
 
-from ..functions.fused import (NormDisparityRegressionFunction, SoftminFunction, normalize_filters,
-                               normalize_guidance, sga_forward_infer)
+from ..functions.fused import (NormDisparityRegressionFunction, SoftminDisparityRegressionFunction, SoftminFunction,
+                               normalize_filters, normalize_guidance, sga_forward_infer)
 from ..functions.GANet import Lga2Function, SgaFunction
 
-__all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "DispAggTail"]
+__all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "SoftminDisparityRegression",
+           "DispAggTail"]
 
 
 class GuidedSGA(Module):
@@ -62,6 +63,18 @@ class NormDisparityRegression(Module):
 
     def forward(self, x):
         return NormDisparityRegressionFunction.apply(x.contiguous(), self.maxdisp)
+
+
+class SoftminDisparityRegression(Module):
+    """Disp.forward after the upsampling (models/GANet_deep.py:217-219): Softmin(dim=1) + DisparityRegression(maxdisp)
+    in one pass over the volume (used for the two auxiliary disparities in training)."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp + 1
+
+    def forward(self, x):
+        return SoftminDisparityRegressionFunction.apply(x.contiguous(), self.maxdisp)
 
 
 class DispAggTail(Module):

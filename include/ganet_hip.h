@@ -181,6 +181,15 @@ int ganet_softmin_forward(const float *x, float *y, int N, int Dn, int H, int W,
 int ganet_softmin_backward(const float *y, const float *grad_y, float *grad_x,
                            int N, int Dn, int H, int W, void *stream);
 
+/* out [N,H,W] = sum_d d * softmin_d(x), x [N,Dn,H,W]: Softmin(dim=1) followed by DisparityRegression as in Disp.forward
+ * (models/GANet_deep.py:217-219) without materialising the probabilities; mx, ssum [N,H,W] (running max of -x and
+ * the sum of exponentials) are kept for the backward, which recomputes them from x. */
+int ganet_softmin_regression_forward(const float *x, float *out, float *mx, float *ssum,
+                                     int N, int Dn, int H, int W, void *stream);
+int ganet_softmin_regression_backward(const float *x, const float *out, const float *mx, const float *ssum,
+                                      const float *grad_out, float *grad_x,
+                                      int N, int Dn, int H, int W, void *stream);
+
 /* ---------------------------------------------------------------- diagnostics ---- */
 
 /* Runs a 64-lane probe of every DPP pattern the kernels rely on and compares with

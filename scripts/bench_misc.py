@@ -63,3 +63,17 @@ res["softmin_fwd"] = (t, 2 * p.numel() * 4 / t / 1e6)
 t = timed(lambda: lib.call("ganet_softmin_backward", sy.data_ptr(), p.data_ptr(), gp.data_ptr(), N, Dn, H, W, st))
 res["softmin_bwd"] = (t, 3 * p.numel() * 4 / t / 1e6)
 print(json.dumps({k: {"ms": round(v[0], 4), "GBps_compulsory": round(v[1], 1)} for k, v in res.items()}))
+res = {}
+mxb, ssb = torch.empty(N, H, W, device=dev), torch.empty(N, H, W, device=dev)
+t = timed(lambda: lib.call("ganet_softmin_regression_forward", p.data_ptr(), out.data_ptr(), mxb.data_ptr(), ssb.data_ptr(), N, Dn, H, W, st))
+res["softmin_regression_fwd"] = (t, p.numel() * 4 / t / 1e6)
+t = timed(lambda: lib.call("ganet_softmin_regression_backward", p.data_ptr(), out.data_ptr(), mxb.data_ptr(), ssb.data_ptr(), go.data_ptr(), gp.data_ptr(), N, Dn, H, W, st))
+res["softmin_regression_bwd"] = (t, 2 * p.numel() * 4 / t / 1e6)
+import torch.nn.functional as F
+xr = p.clone().requires_grad_()
+disp = torch.arange(Dn, device=dev, dtype=torch.float32).view(1, Dn, 1, 1)
+def ref():
+    o = torch.sum(F.softmin(xr, dim=1) * disp, 1)
+    torch.autograd.grad(o, [xr], go)
+res["torch_softmin_regression_fwd_bwd"] = (timed(ref), 0.0)
+print(json.dumps({k: {"ms": round(v[0], 4), "GBps_compulsory": round(v[1], 1)} for k, v in res.items()}))

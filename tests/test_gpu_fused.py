@@ -142,3 +142,21 @@ def test_guided_sga_bn_relu_eval_matches_op_chain(torch_mod, port_oracle):
     y.sum().backward()
     assert x.grad is not None and g.grad is not None
     assert np.abs(_np(y) - want.numpy()).max() <= pc.TOL
+
+
+def test_softmin_disparity_regression_full_size(torch_mod):
+    """SoftminDisparityRegression on [1,193,240,624] == Softmin(dim=1) + DisparityRegression (models/GANet_deep.py:217-219)
+    computed with torch's own ops on the GPU, forward and backward."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import SoftminDisparityRegression
+    torch.manual_seed(2)
+    x = (3 * torch.randn(1, 193, 240, 624, device="cuda")).requires_grad_()
+    go = torch.randn(1, 240, 624, device="cuda")
+    out = SoftminDisparityRegression(192)(x)
+    out.backward(go)
+    x2 = x.detach().clone().requires_grad_()
+    disp = torch.arange(193, device="cuda", dtype=torch.float32).view(1, 193, 1, 1)
+    ref = torch.sum(torch.nn.functional.softmin(x2, dim=1) * disp, 1)
+    ref.backward(go)
+    np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-4)
+    assert (x.grad - x2.grad).abs().max().item() <= 1e-4 * max(1.0, x2.grad.abs().max().item())

@@ -131,3 +131,22 @@ def test_softmin_forward_backward(sim, N, D, H, W):
     sim.call("ganet_softmin_backward", _p(y_ref), _p(gy), _p(gx), N, D, H, W, None)
     # (gy_d - sum gy*y cancels where y ~ 1: the order of the 193-term dot product shows up at the 1e-6 level)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,maxdisp,H,W", [(1, 6, 3, 5), (2, 192, 2, 3)])
+def test_softmin_disparity_regression(sim, N, maxdisp, H, W):
+    """Disp.forward lines models/GANet_deep.py:217-219 (Softmin(dim=1) + DisparityRegression) in one pass, vs torch."""
+    rng = np.random.default_rng(maxdisp + 1)
+    D = maxdisp + 1
+    x = (rng.standard_normal((N, D, H, W)) * 3).astype(np.float32)
+    x[0, :, 0, 0] *= 15.0
+    go = rng.standard_normal((N, H, W)).astype(np.float32)
+    out, mx, ss = (np.full((N, H, W), np.nan, np.float32) for _ in range(3))
+    sim.call("ganet_softmin_regression_forward", _p(x), _p(out), _p(mx), _p(ss), N, D, H, W, None)
+    tx = torch.from_numpy(x).requires_grad_()
+    want = fr.disparity_regression(torch.nn.functional.softmin(tx, dim=1), maxdisp)
+    np.testing.assert_allclose(out, want.detach().numpy(), rtol=1e-5, atol=1e-4)
+    want.backward(torch.from_numpy(go))
+    gx = np.full_like(x, np.nan)
+    sim.call("ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ss), _p(go), _p(gx), N, D, H, W, None)
+    np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
