@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     lo, hi = gdist.shard_range(7, ctx)
     grads = [torch.full((5,), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))]
     gdist.all_reduce_mean_(grads, ctx, bucket_bytes=16)
-    q.put((rank, t, (lo, hi), [g.clone() for g in grads]))
+    q.put((rank, t, (lo, hi), [g.tolist() for g in grads]))      # plain lists: a tensor in the queue is handed over
+    # through the sender's resource-sharer socket, which is gone if this process exits before the parent reads it
     gdist.finish(ctx)
 
 
@@ -50,8 +51,8 @@ def test_two_rank_timing_sharding_and_grad_mean():
     assert abs(t0 - t1) < 1e-9 and t0 >= 0.25, "every rank must see the max-over-ranks time"
     assert res[0][2] == (0, 4) and res[1][2] == (4, 7)
     for _, _, _, grads in res:
-        assert torch.allclose(grads[0], torch.full((5,), 1.5))
-        assert torch.allclose(grads[1], torch.full((3, 2), 15.0))
+        assert torch.allclose(torch.tensor(grads[0]), torch.full((5,), 1.5))
+        assert torch.allclose(torch.tensor(grads[1]), torch.full((3, 2), 15.0))
 
 
 def test_world_size_mismatch_is_an_error(monkeypatch):
