@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.ganet_is_simulator() == 0
 
 
+def test_ctypes_prototypes_match_the_header():
+    """Every prototype in include/ganet_hip.h has as many parameters -- pointers and ints in the same positions -- as its
+    ctypes declaration in ganet_amd/_native.py (a drift between the two corrupts the call silently)."""
+    from ganet_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "ganet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = dict(re.findall(r"\bint\s+(ganet_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S))
+    assert set(protos) == set(_native._PROTOS), set(protos) ^ set(_native._PROTOS)
+    for name, params in protos.items():
+        params = params.strip()
+        plist = [] if params in ("", "void") else [q.strip() for q in params.split(",")]
+        kinds = [ctypes.c_void_p if "*" in q else ctypes.c_int for q in plist]
+        want = [ctypes.c_void_p if a in (ctypes.c_void_p, ctypes.c_char_p) else a for a in _native._PROTOS[name]]
+        assert kinds == want, (name, plist)
+
+
 def test_library_contains_gfx950_code_object(built_lib):
     blob = open(built_lib, "rb").read()
     assert b"gfx950" in blob, "no gfx950 code object in libganet_hip.so"
