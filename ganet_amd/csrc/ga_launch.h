@@ -48,6 +48,7 @@ inline int row_dpl(int D)
 }
 
 // sga_row_fwd_tu.hip: horizontal forward scans (direction 2 = right, 3 = left); the caller checks the launch
-void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st);
+void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
+                    int out_mode = 0, int C = 1, const float *scale = nullptr, const float *shift = nullptr);
 
 }  // namespace ga

@@ -23,6 +23,7 @@ namespace ga {
 struct ColGeom {
   int D, H, W;
   i64 HW;
+  int out_mode;     // forward scans: 0  A = tile;  1  A = max(A, tile) (running direction max, inference path)
 };
 
 constexpr int COL_SBV = 4;     // rows (scan positions) per staged batch = one ds_read_b128
@@ -158,7 +159,13 @@ sga_col_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
         o.y = at[((4 * piece + 1) * D + d) * SB + j];
         o.z = at[((4 * piece + 2) * D + d) * SB + j];
         o.w = at[((4 * piece + 3) * D + d) * SB + j];
-        *reinterpret_cast<f4 *>(A + sbase + (i64)d * geo.HW + (i64)row * W + c0 + 4 * piece) = o;
+        float *dst = A + sbase + (i64)d * geo.HW + (i64)row * W + c0 + 4 * piece;
+        if (geo.out_mode) {                        // (uniform) running max into the output volume
+          const f4 p_ = *reinterpret_cast<const f4 *>(dst);
+          o.x = o.x < p_.x ? p_.x : o.x; o.y = o.y < p_.y ? p_.y : o.y;
+          o.z = o.z < p_.z ? p_.z : o.z; o.w = o.w < p_.w ? p_.w : o.w;
+        }
+        *reinterpret_cast<f4 *>(dst) = o;
       }
     }
     GA_LDS_BARRIER();

@@ -8,10 +8,12 @@
 
 namespace ga {
 
-void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
+void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
+                    int out_mode, int C, const float *scale, const float *shift)
 {
   RowGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
+  geo.out_mode = out_mode; geo.C = C > 0 ? C : 1; geo.scale = scale; geo.shift = shift;
   const int dpl = row_dpl(D);
   const bool full = dpl > 0 && D % dpl == 0;     // lanes wholly inside / outside [0, D): leaner recurrence
   const size_t smem = row_smem_fwd(D);

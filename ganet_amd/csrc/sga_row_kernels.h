@@ -37,6 +37,12 @@ struct RowGeom {
   int D, H, W;
   int total_rows;   // S * H
   i64 HW;
+  // forward scans only -- what the copy-out does with the finished tile (inference path, ganet_sga_forward_infer):
+  //   0  A = tile;   1  A = max(A, tile)  (running direction max, A is the output volume);
+  //   2  A = relu(scale[c] * max(A, tile) + shift[c])  (last direction + eval-mode BatchNorm3d + ReLU)
+  int out_mode;
+  int C;                       // channels per sample (slice % C indexes scale / shift)
+  const float *scale, *shift;
 };
 
 template <int SBH, int PAD> struct RowCfg {
@@ -70,6 +76,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   c.lg = rl; c.d0 = d0; c.line_ok = true; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   const int piece = lane % C::PP, psub = lane / C::PP;
   i64 vb[LN], gbo[LN];
+  float bn_sc[LN], bn_sh[LN];
   bool rok[LN];
 #pragma unroll
   for (int q = 0; q < LN; q++) {
@@ -79,6 +86,8 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
     const int s = row / geo.H, h = row - s * geo.H;
     vb[q] = (i64)s * D * geo.HW + (i64)h * W;
     gbo[q] = (i64)s * 5 * geo.HW + (i64)h * W;
+    bn_sc[q] = 1.f; bn_sh[q] = 0.f;
+    if (geo.out_mode == 2) { bn_sc[q] = geo.scale[s % geo.C]; bn_sh[q] = geo.shift[s % geo.C]; }
   }
   // Line-aligned batches: a batch covers SBH elements that start on a multiple of SBH elements of the
   // ADDRESS (one or two whole 128-byte lines per plane), not of the row.  Rows of W = 208 floats start
@@ -187,9 +196,19 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 #pragma unroll
       for (int n = 0; n < NPC; n++) {
         const int pl = n * C::PPI + psub;
-        if (pl < D && col_ok && rok[q])
-          *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) =
-              *reinterpret_cast<const f4 *>(at + (q * D + pl) * C::RS + 4 * piece);
+        if (pl < D && col_ok && rok[q]) {
+          f4 v = *reinterpret_cast<const f4 *>(at + (q * D + pl) * C::RS + 4 * piece);
+          if (geo.out_mode) {                      // (uniform) running max into the output volume
+            const f4 o = *reinterpret_cast<const f4 *>(Ab + (i64)pl * geo.HW + wq);
+            v.x = v.x < o.x ? o.x : v.x; v.y = v.y < o.y ? o.y : v.y;
+            v.z = v.z < o.z ? o.z : v.z; v.w = v.w < o.w ? o.w : v.w;
+            if (geo.out_mode == 2) {
+              v.x = fmaxf(fmaf(v.x, bn_sc[q], bn_sh[q]), 0.f); v.y = fmaxf(fmaf(v.y, bn_sc[q], bn_sh[q]), 0.f);
+              v.z = fmaxf(fmaf(v.z, bn_sc[q], bn_sh[q]), 0.f); v.w = fmaxf(fmaf(v.w, bn_sc[q], bn_sh[q]), 0.f);
+            }
+          }
+          *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) = v;
+        }
       }
     }
     GA_WAVE_SYNC();

@@ -61,7 +61,8 @@ int ganet_sga_forward(const float *x, const float *g0, const float *g1, const fl
                       int N, int C, int D, int H, int W, void *stream);
 
 /* Inference-only forward: out = relu(bn_scale[c] * max_dir A_dir + bn_shift[c]) (bn_scale = bn_shift = NULL:
- * plain max).  No mask / arg-max is produced and A_ws ([4][N*C*D*H*W]) is scratch.
+ * plain max).  No mask / arg-max is produced; A_ws ([4][N*C*D*H*W]) is scratch and stays untouched when the scans can take
+ * the running maximum themselves (the usual case: W % 4 == 0, D <= 208, 16-byte aligned buffers).
  * Replaces: sga_kernel_forward (GANet_kernel.cu:935-998) followed by the eval-mode BatchNorm3d + ReLU of
  * SGABlock.forward (models/GANet_deep.py:269-271: `x = self.SGA(...); x = self.bn_relu(x)`), with
  * bn_scale = weight / sqrt(running_var + eps), bn_shift = bias - running_mean * bn_scale. */
