@@ -297,7 +297,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread_local: with N > 1 ranks the RCCL watchdog thread polls events while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 keep = one_step(inp)          # outputs stay alive inside the graph's pool
             launch_mode = "hipGraph replay"
         except Exception as e:            # capture unsupported: fall back to eager launches
@@ -351,7 +352,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(cap)
                 torch.cuda.synchronize()
                 g2s = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2s):
+                with torch.cuda.graph(g2s, capture_error_mode="thread_local"):
                     keep2 = one_step_two_streams(inp, side2)
                 for _ in range(args.warmup):
                     g2s.replay()
