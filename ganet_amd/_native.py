@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -24,6 +24,7 @@ _PROTOS = {
     "ganet_sga_scan_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ganet_sga_forward": [_P] * 9 + [_I] * 5 + [_P],
     "ganet_sga_forward_infer": [_P] * 9 + [_I] * 5 + [_P],
+    "ganet_sga_forward_infer_scratch": [_P] * 6 + [_I] * 5,
     "ganet_sga_backward_scan": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_sga_backward_dir": [_P] * 9 + [_I] * 7 + [_P],
     "ganet_sga_backward": [_P] * 15 + [_I] * 5 + [_P],
@@ -80,6 +81,13 @@ class CApi:
         rc = getattr(self._lib, name)(*args)
         if rc != 0:
             raise GanetError(f"{name} failed ({rc}): {self.last_error()}")
+
+    def query(self, name, *args):
+        """entry points that answer with a non-negative number"""
+        rc = getattr(self._lib, name)(*args)
+        if rc < 0:
+            raise GanetError(f"{name} failed ({rc}): {self.last_error()}")
+        return rc
 
     def set_option(self, name, value):
         self.call("ganet_set_option", name.encode(), int(value))

@@ -15,7 +15,8 @@ SOURCES = {
 }
 HEADERS = ["ga_common.h", "ga_launch.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "lga_kernels.h",
            "misc_kernels.h"]
-OUT = os.path.join(_HERE, "libganet_hip.so")
+LIB_SONAME = "libganet_hip.so"
+OUT = os.path.join(_HERE, LIB_SONAME)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
 
@@ -30,7 +31,7 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> libganet_hip.so.  hipcc cross-compiles without a GPU."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     deps = [os.path.join(CSRC, f) for f in list(SOURCES) + HEADERS]
-    deps.append(os.path.join(os.path.dirname(_HERE), "include", "ganet_hip.h"))
+    deps += [os.path.join(os.path.dirname(_HERE), "include", "ganet_hip.h"), os.path.abspath(__file__)]
     if not force and not _stale(out, deps):
         return out
     if not os.path.exists(hipcc):
@@ -48,7 +49,7 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + LIB_SONAME] + objs + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -58,5 +59,56 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
     return out
 
 
+EXT_SRC = os.path.join(CSRC, "ganet_torch_ext.cpp")
+# where the reference's `from ..build.lib import GANet` (libs/GANet/functions/GANet.py:3) looks
+EXT_DIR = os.path.join(os.path.dirname(_HERE), "libs", "GANet", "build", "lib")
+
+
+def ext_path():
+    import sysconfig
+    return os.path.join(EXT_DIR, "GANet" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_torch_ext(force=False, verbose=False):
+    """The pybind module `GANet` (csrc/ganet_torch_ext.cpp: the reference's six-function native surface on top of the
+    C ABI) -> libs/GANet/build/lib/GANet.<abi>.so.  Host-only C++ (no device code): g++ against the torch headers,
+    linked to libganet_hip.so by rpath: next to the module ($ORIGIN, for a copy into a GANet checkout's
+    libs/GANet/build/lib/ together with libganet_hip.so) or in this tree's ganet_amd/."""
+    out = ext_path()
+    deps = [EXT_SRC, os.path.join(os.path.dirname(_HERE), "include", "ganet_hip.h"), os.path.abspath(__file__)]
+    if not force and not _stale(out, deps):
+        return out
+    cxx = shutil.which("g++")
+    if cxx is None:
+        if os.path.exists(out):
+            return out
+        raise RuntimeError("g++ not found and no prebuilt GANet extension module")
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    os.makedirs(EXT_DIR, exist_ok=True)
+    for d in (os.path.dirname(EXT_DIR), EXT_DIR):             # `..build.lib` must be a package chain
+        init = os.path.join(d, "__init__.py")
+        if not os.path.exists(init):
+            open(init, "w").close()
+    inc = ce.include_paths("cuda") if "device_type" in ce.include_paths.__code__.co_varnames else ce.include_paths(True)
+    inc = [i for i in inc if os.path.isdir(i)] + [sysconfig.get_paths()["include"]]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-deprecated-declarations",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=GANet", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for i in inc:
+        cmd += ["-isystem", i]
+    cmd += [EXT_SRC, "-o", out + ".tmp", "-L", tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+            "-ltorch_python", "-L", _HERE, "-lganet_hip",
+            "-Wl,-rpath,$ORIGIN:$ORIGIN/../../../../ganet_amd", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_torch_ext(force=True, verbose=True))

@@ -4,6 +4,7 @@
 #pragma once
 #include "ga_common.h"
 #include "sga_row_kernels.h"
+#include <stdio.h>
 
 #if defined(GA_HIPSIM)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
@@ -12,12 +13,24 @@
   hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 #define GA_EXPORT extern "C"
 #else
-// hipGetLastError() is per-thread state shared with the host framework: drop whatever an earlier,
-// unrelated HIP call left there so check_launch() reports THIS launch
+// hipGetLastError() is per-thread state shared with the host framework.  An error some earlier, unrelated HIP call left
+// there must not be blamed on THIS launch -- and must not vanish either: ga_note_stale_error() reports it on stderr
+// (once per thread and error code) before the state is cleared.
+inline void ga_note_stale_error()
+{
+  if (hipPeekAtLastError() == hipSuccess) return;
+  const hipError_t e = hipGetLastError();
+  static thread_local hipError_t last_reported = hipSuccess;
+  if (e != last_reported) {
+    last_reported = e;
+    fprintf(stderr, "libganet_hip: HIP error \"%s\" was already pending on this thread before a ganet launch "
+                    "(left by an earlier call of the host framework); cleared\n", hipGetErrorString(e));
+  }
+}
 #define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
-  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
+  do { ga_note_stale_error(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
-  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
+  do { ga_note_stale_error(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
 #define GA_EXPORT extern "C" __attribute__((visibility("default")))
 #endif
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/ganet_hip.h"
@@ -58,27 +59,28 @@ int check_launch(const char *what)
 // want FEW lanes per scanline (GD=4: each wave load covers 64 contiguous bytes per plane),
 // horizontal scans want many (GD=16: more waves, float4 per lane along W).  Running the four
 // directions on four streams was slower than back-to-back launches (0.97 vs 0.87 ms).
+// Fields are atomics: ganet_set_option() may race with launches on other threads (each launcher reads a field once).
 struct Options {
-  int gd_v = 4;
-  int gd_h = 16;
-  int streams = 0;
-  int lga_wave = 2;   // LGA forward / data-backward: 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
-  int lga_segs = 0;   // depth segments per tile for those kernels (0 = automatic)
-  int lga_split = 1;  // automatic mode: unequal two-way depth split sized to the wave slots (LgaSeg::split_a)
-  int rowwave = 1;      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
-  int colblock = 1;     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
-  int point_block = 256;   // threads per block of the per-pixel gradient kernel
-  int infer_fused = 1;  // ganet_sga_forward_infer: running direction max inside the scans (no directional volumes)
-  int merge4 = 1;       // merge + arg-max: four pixels per lane (16-byte requests)
-  int block_v = 128;
-  int block_h = 64;
+  std::atomic<int> gd_v{4};
+  std::atomic<int> gd_h{16};
+  std::atomic<int> streams{0};
+  std::atomic<int> lga_wave{2};   // LGA forward / data-backward: 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_segs{0};   // depth segments per tile for those kernels (0 = automatic)
+  std::atomic<int> lga_split{1};  // automatic mode: unequal two-way depth split sized to the wave slots (LgaSeg::split_a)
+  std::atomic<int> rowwave{1};      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
+  std::atomic<int> colblock{1};     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
+  std::atomic<int> point_block{256};   // threads per block of the per-pixel gradient kernel
+  std::atomic<int> infer_fused{1};  // ganet_sga_forward_infer: running direction max inside the scans (no directional volumes)
+  std::atomic<int> merge4{1};       // merge + arg-max: four pixels per lane (16-byte requests)
+  std::atomic<int> block_v{128};
+  std::atomic<int> block_h{64};
 };
 Options g_opt;
 std::once_flag g_opt_once;
 
 void load_env_options()
 {
-  auto geti = [](const char *name, int &dst) {
+  auto geti = [](const char *name, std::atomic<int> &dst) {
     const char *v = getenv(name);
     if (v && *v) dst = atoi(v);
   };
@@ -646,12 +648,31 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   return check_launch("sga merge");
 }
 
+namespace {
+bool infer_fused_ok(const float *x, const float *g0, const float *g1, const float *g2, const float *g3, const float *out,
+                    int N, int C, int D, int W)
+{
+  const bool all_al = aligned16(x) && aligned16(out) && aligned16(g0) && aligned16(g1) && aligned16(g2) && aligned16(g3);
+  return opts().infer_fused && all_al && N * C <= 65535 && rowwave_ok(D, W, 2, row_smem_fwd(D)) &&
+         colblock_ok(D, W, 0, col_smem_fwd(D));
+}
+}  // namespace
+
+GA_EXPORT int ganet_sga_forward_infer_scratch(const float *x, const float *g0, const float *g1, const float *g2,
+                                              const float *g3, const float *out, int N, int C, int D, int H, int W)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !out)
+    return fail(GANET_E_INVALID, "ganet_sga_forward_infer_scratch: null pointer");
+  GA_TRY(check_dims5("ganet_sga_forward_infer_scratch", N, C, D, H, W));
+  return infer_fused_ok(x, g0, g1, g2, g3, out, N, C, D, W) ? 0 : 4;
+}
+
 GA_EXPORT int ganet_sga_forward_infer(const float *x, const float *g0, const float *g1, const float *g2,
                                       const float *g3, float *A_ws, float *out, const float *bn_scale,
                                       const float *bn_shift, int N, int C, int D, int H, int W,
                                       void *stream)
 {
-  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out)
+  if (!x || !g0 || !g1 || !g2 || !g3 || !out)
     return fail(GANET_E_INVALID, "ganet_sga_forward_infer: null pointer");
   if ((bn_scale == nullptr) != (bn_shift == nullptr))
     return fail(GANET_E_INVALID, "ganet_sga_forward_infer: bn_scale and bn_shift go together");
@@ -663,14 +684,13 @@ GA_EXPORT int ganet_sga_forward_infer(const float *x, const float *g0, const flo
   // Fast form: no directional volume is kept.  `down` writes the output volume, `up` / `right` / `left` take the running
   // maximum in the copy-out of their tiles, `left` also applies the BatchNorm affine + ReLU: 11 V of traffic and four
   // launches instead of 13 V and five (A_ws is not touched).
-  const bool all_al = aligned16(x) && aligned16(out) && aligned16(g0) && aligned16(g1) && aligned16(g2) && aligned16(g3);
-  if (opts().infer_fused && all_al && N * C <= 65535 && rowwave_ok(D, W, 2, row_smem_fwd(D)) &&
-      colblock_ok(D, W, 0, col_smem_fwd(D))) {
+  if (infer_fused_ok(x, g0, g1, g2, g3, out, N, C, D, W)) {
     GA_TRY(col_fwd(x, g0, out, N * C, D, H, W, 0, st, 0));
     GA_TRY(col_fwd(x, g1, out, N * C, D, H, W, 1, st, 1));
     GA_TRY(row_fwd(x, g2, out, N * C, D, H, W, 2, st, 1));
     return row_fwd(x, g3, out, N * C, D, H, W, 3, st, bn_scale ? 2 : 1, C, bn_scale, bn_shift);
   }
+  if (!A_ws) return fail(GANET_E_INVALID, "ganet_sga_forward_infer: this shape needs the A_ws scratch (see ganet_sga_forward_infer_scratch)");
   for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   if (slice % 4 == 0 && aligned16(A_ws) && aligned16(out))
     GA_LAUNCH((sga_merge_infer<true>), dim3(ew_grid(n / 4)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n, A_ws + 3 * n,

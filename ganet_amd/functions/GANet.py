@@ -38,7 +38,8 @@ def _check(*tensors):
             raise TypeError(f"ganet_amd ops are fp32 only, got {t.dtype}")
         if t.device != dev:
             raise RuntimeError("all tensors of a ganet_amd op must live on one device")
-        assert t.is_contiguous(), "ganet_amd ops need contiguous tensors"   # functions/GANet.py:11
+        if not t.is_contiguous():     # the reference asserts (functions/GANet.py:11); an assert vanishes under python -O
+            raise RuntimeError("ganet_amd ops need contiguous tensors")
 
 
 def _stream():
@@ -67,6 +68,15 @@ class SgaFunction(Function):
         ctx.recompute = os.environ.get("GANET_SGA_SAVE", "") == "recompute"
         with torch.cuda.device_of(input):
             output = torch.empty_like(input)
+            if not any(ctx.needs_input_grad):
+                # nothing to differentiate (torch.no_grad() as in predict.py:113, or no input requires grad): the scans keep
+                # a running direction maximum -- four launches, no directional volumes, no mask / arg-max kept
+                nws = _lib().query("ganet_sga_forward_infer_scratch", _p(input), _p(g0), _p(g1), _p(g2), _p(g3),
+                                   _p(output), N, C, D, H, W)
+                A = torch.empty((nws,) + tuple(input.shape), dtype=input.dtype, device=input.device) if nws else None
+                _lib().call("ganet_sga_forward_infer", _p(input), _p(g0), _p(g1), _p(g2), _p(g3),
+                            _p(A) if nws else 0, _p(output), 0, 0, N, C, D, H, W, _stream())
+                return output
             if ctx.recompute:
                 temp_out = torch.empty_like(input)
                 mask = torch.empty_like(input)
@@ -259,7 +269,9 @@ class MyLoss2Function(Function):
         scale[tag] = 2 * scale[tag] / ctx.thresh
         sign = torch.sign(diff)
         grad = sign * scale * gradOutput / scale.numel()
-        return grad, None, None, None
+        # the reference hands back a one-element zero tensor for input2 (functions/GANet.py:289): the target never
+        # receives a gradient; here: zeros of the right shape when autograd asks for one, else None
+        return grad, (torch.zeros_like(diff) if ctx.needs_input_grad[1] else None), None, None
 
 
 class MyLossFunction(Function):
@@ -280,4 +292,4 @@ class MyLossFunction(Function):
         tag = (scale <= ctx.upper_thresh) & (scale >= ctx.lower_thresh)
         scale[tag] = 2 - torch.abs(scale[tag] - (ctx.upper_thresh + ctx.lower_thresh) / 2.) / 2.
         grad = torch.sign(diff) * scale * gradOutput
-        return grad, None, None, None
+        return grad, (torch.zeros_like(diff) if ctx.needs_input_grad[1] else None), None, None   # functions/GANet.py:310

@@ -115,9 +115,10 @@ def sga_forward_infer(x, g0, g1, g2, g3, bn_scale=None, bn_shift=None):
     if bn_scale is not None and (bn_scale.numel() != C or bn_shift.numel() != C):
         raise ValueError("bn_scale / bn_shift must have one entry per channel")
     with torch.cuda.device_of(x):
-        A = torch.empty((4,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         out = torch.empty_like(x)
-        _lib().call("ganet_sga_forward_infer", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(A), _p(out),
+        nws = _lib().query("ganet_sga_forward_infer_scratch", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(out), N, C, D, H, W)
+        A = torch.empty((nws,) + tuple(x.shape), dtype=x.dtype, device=x.device) if nws else None
+        _lib().call("ganet_sga_forward_infer", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(A) if nws else None, _p(out),
                     _p(bn_scale) if bn_scale is not None else None, _p(bn_shift) if bn_shift is not None else None,
                     N, C, D, H, W, _stream())
     return out

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 3
+#define GANET_ABI_VERSION 4
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -69,6 +69,10 @@ int ganet_sga_forward(const float *x, const float *g0, const float *g1, const fl
 int ganet_sga_forward_infer(const float *x, const float *g0, const float *g1, const float *g2,
                             const float *g3, float *A_ws, float *out, const float *bn_scale,
                             const float *bn_shift, int N, int C, int D, int H, int W, void *stream);
+/* How many volume-sized ([N*C*D*H*W] floats) scratch buffers ganet_sga_forward_infer needs behind A_ws for these
+ * arguments: 0 (the scans take the running maximum themselves; A_ws may then be NULL) or 4.  Negative on error. */
+int ganet_sga_forward_infer_scratch(const float *x, const float *g0, const float *g1, const float *g2,
+                                    const float *g3, const float *out, int N, int C, int D, int H, int W);
 
 /* Reverse-scan adjoint of one direction: G = [mask == dir] * grad_out propagated through the
  * recurrence with first-argmax routing (kp_dir: [N*C*H*W] uint16 of that direction).

@@ -61,3 +61,27 @@ def test_world_size_mismatch_is_an_error(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     with pytest.raises(RuntimeError, match="torch.distributed.run"):
         gdist.init(4)
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_gpus2_plumbing_with_stub_step(launcher):
+    """`python bench.py --gpus 2` must work BOTH ways: on its own (it re-executes itself under torch.distributed.run)
+    and when the driver launches it under torch.distributed.run -- here on CPU/gloo with the placeholder step
+    (--stub-step); exactly one JSON line, from rank 0, with the protocol's fields."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    tail = [bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]

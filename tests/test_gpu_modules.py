@@ -184,3 +184,55 @@ def test_sga_on_16_byte_aligned_views(torch_mod, port_oracle, offset):
     assert np.array_equal(_np(out), o_out)
     for got, want in zip(grads, o_g):
         assert np.abs(_np(got) - want).max() <= pc.TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 33, 10, 24), (1, 2, 9, 5, 7), (1, 1, 240, 4, 12)])
+def test_sga_without_grad_takes_the_inference_path(torch_mod, port_oracle, shape):
+    """Under torch.no_grad() (predict.py:113) or when no input needs a gradient, SgaFunction keeps nothing for a
+    backward and runs the four-launch running-maximum form; its output is the same bit-exact volume.  Shapes: the
+    fused scans' range, W % 4 != 0 and D > 208 (both need the scratch volumes)."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.functions.GANet import SgaFunction
+    torch.manual_seed(sum(shape))
+    N, C, D, H, W = shape
+    x = torch.randn(shape, device="cuda")
+    gs = [F.normalize(torch.randn(N, C, 5, H, W, device="cuda"), p=1, dim=2) for _ in range(4)]
+    want, _, _ = port_oracle.sga_forward(_np(x), *[_np(g) for g in gs])
+    out_plain = SgaFunction.apply(x, *gs)                    # nothing requires grad
+    assert out_plain.grad_fn is None
+    with torch.no_grad():
+        out_ng = SgaFunction.apply(x.clone().requires_grad_(), *gs)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(out_plain), want) and np.array_equal(_np(out_ng), want)
+    before = torch.cuda.memory_allocated()
+    out = SgaFunction.apply(x, *gs)
+    torch.cuda.synchronize()
+    if W % 4 == 0 and D <= 208:     # no directional volumes / mask / arg-max were kept or allocated
+        assert torch.cuda.memory_allocated() - before <= x.numel() * 4 + 4096
+    del out
+
+
+def test_loss_functions_on_gpu_match_cpu(torch_mod):
+    """MyLoss2 / MyLoss (functions/GANet.py:264-310) are plain tensor statements: GPU == CPU, the gradient follows the
+    reference's scale table, and a target that asks for a gradient gets zeros (the reference hands back a one-element
+    zero tensor there)."""
+    torch = torch_mod
+    from ganet_amd.modules.GANet import MyLoss, MyLoss2
+    torch.manual_seed(0)
+    a = (torch.randn(4000, device="cuda") * 4).requires_grad_()
+    b = torch.randn(4000, device="cuda") * 4
+    loss = MyLoss2(thresh=3, alpha=2)(a, b)
+    loss.backward()
+    ac = a.detach().cpu().requires_grad_()
+    lc = MyLoss2(thresh=3, alpha=2)(ac, b.cpu())
+    lc.backward()
+    assert abs(loss.item() - lc.item()) <= 1e-5 * max(1.0, abs(lc.item()))
+    assert (a.grad.cpu() - ac.grad).abs().max().item() <= 1e-7
+    d = (a.detach() - b).abs()
+    t, al = 3.0, 2.0
+    scale = torch.where(d < t, 2 * d / t, torch.where(d <= t + al, 2 - (d - t) / al, torch.ones_like(d)))
+    assert (a.grad - torch.sign(a.detach() - b) * scale / a.numel()).abs().max().item() <= 1e-6
+    a2, b2 = a.detach().clone().requires_grad_(), b.clone().requires_grad_()
+    MyLoss()(a2, b2).backward()
+    assert b2.grad is not None and float(b2.grad.abs().max()) == 0.0

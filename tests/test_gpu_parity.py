@@ -323,3 +323,87 @@ def test_random_shape_fuzz_against_oracle(api, dev, port_oracle):
         y, ins = port_oracle.lga_chain_forward(x, f, r, passes)
         gx, gf = port_oracle.lga_chain_backward(ins, f, gy, r)
         pc.check_lga_chain(api, dev, x, f, gy, r, passes, {"y": y, "gx": gx, "gf": gf})
+
+
+# ---- every model shape of BASELINE configs 2-5 against the ORACLE (not only family vs family) -------------------------
+
+@pytest.mark.parametrize("shape", [(1, 48, 33, 40, 104), (1, 32, 65, 128, 416), (1, 48, 33, 64, 208),
+                                   (2, 32, 65, 176, 320), (2, 48, 33, 88, 160)])
+def test_sga_model_shapes_vs_oracle(api, dev, port_oracle, shape):
+    """The SGA volumes GANet-deep feeds the op at cfg2/4 (1/6-res), cfg3 (KITTI 1248x384: 1/3- and 1/6-res) and cfg5
+    (SceneFlow 960x528, two samples per GPU): forward volumes / mask / arg-max bit-exact, gradients within 1e-4 of
+    the CPU oracle on the same seeded inputs."""
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    err = pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go), per_dir=False)
+    print("SGA", shape, "max-abs errors:", err)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 240, 12, 24), (1, 1, 209, 6, 16), (1, 1, 272, 5, 20)])
+def test_sga_deep_volumes_segment_fallback_vs_oracle(api, dev, port_oracle, shape):
+    """D > 208 leaves the LDS-staged scans' range: the segment kernels take over for D in (208, 272] -- same bar
+    against the oracle."""
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+
+
+def _lga_vs_oracle(api, dev, oracle, x, f, gy, r, passes):
+    y, ins = oracle.lga_chain_forward(x, f, r, passes)
+    gx, gf = oracle.lga_chain_backward(ins, f, gy, r)
+    return pc.check_lga_chain(api, dev, x, f, gy, r, passes, {"y": y, "gx": gx, "gf": gf})
+
+
+@pytest.mark.parametrize("shape", [(1, 193, 384, 1248), (2, 193, 528, 960)])
+def test_lga_model_shapes_vs_oracle(api, dev, port_oracle, shape):
+    """LGA2 (radius 2, two chained passes) at the cfg3 and cfg5 shapes against the oracle: y, gX, gF within 1e-4."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((shape[0], 75) + shape[2:]), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    print("LGA2", shape, "max-abs errors:", _lga_vs_oracle(api, dev, port_oracle, x, f, gy, 2, 2))
+
+
+def test_lga_post_softmin_input_full_size_vs_oracle(api, dev, port_oracle):
+    """SURVEY 8d's second LGA input: pass-2-like x = softmax(-randn) over the disparity axis (what DispAgg feeds the
+    second LGA2 after nn.Softmin, models/GANet_deep.py:244-245), full cfg2 size."""
+    rng = np.random.default_rng(77)
+    shape = (1, 193, 240, 624)
+    z = -rng.standard_normal(shape)
+    z = np.exp(z - z.max(1, keepdims=True))
+    x = (z / z.sum(1, keepdims=True)).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((1, 75, 240, 624)), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    print("LGA2 post-softmin max-abs errors:", _lga_vs_oracle(api, dev, port_oracle, x, f, gy, 2, 2))
+
+
+def test_cost_volume_and_regression_cfg2_size(api, dev, port_oracle):
+    """GetCostVolume [1,32,80,208] x2 -> [1,64,65,80,208] forward (bit-exact: pure copies) and backward (sums of up to
+    65 terms: 1e-4), DisparityRegression [1,193,240,624] forward and backward, against the oracle / its adjoint."""
+    rng = np.random.default_rng(5)
+    N, C, H, W, maxdisp = 1, 32, 80, 208, 64
+    Dn = maxdisp + 1
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dx, dy = dev.to(x), dev.to(y)
+    cost = dev.empty((N, 2 * C, Dn, H, W))
+    api.call("ganet_cost_volume_forward", dx.data_ptr(), dy.data_ptr(), cost.data_ptr(), N, C, Dn, H, W, dev.stream)
+    want = port_oracle.cost_volume(x, y, maxdisp)
+    assert np.array_equal(dev.host(cost), want)
+    gc = rng.standard_normal(want.shape).astype(np.float32)
+    gx, gy = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+    api.call("ganet_cost_volume_backward", dev.to(gc).data_ptr(), gx.data_ptr(), gy.data_ptr(), N, C, Dn, H, W, dev.stream)
+    # adjoint of the copies (modules/GANet.py:125-131): x feeds cost[:, :C, i, :, i:], y feeds cost[:, C:, i, :, i:] shifted by i
+    wx = np.zeros((N, C, H, W), np.float64)
+    wy = np.zeros((N, C, H, W), np.float64)
+    for i in range(Dn):
+        wx[..., i:] += gc[:, :C, i, :, i:]
+        wy[..., :W - i] += gc[:, C:, i, :, i:]
+    assert np.abs(dev.host(gx) - wx).max() <= pc.TOL and np.abs(dev.host(gy) - wy).max() <= pc.TOL
+    p = rng.random((1, 193, 240, 624)).astype(np.float32)
+    p /= p.sum(1, keepdims=True)
+    out = dev.empty((1, 240, 624))
+    api.call("ganet_disparity_regression_forward", dev.to(p).data_ptr(), out.data_ptr(), 1, 193, 240, 624, dev.stream)
+    np.testing.assert_allclose(dev.host(out), port_oracle.disparity_regression(p, 192), rtol=1e-5, atol=1e-4)
+    go = rng.standard_normal((1, 240, 624)).astype(np.float32)
+    gp = dev.empty(p.shape)
+    api.call("ganet_disparity_regression_backward", dev.to(go).data_ptr(), gp.data_ptr(), 1, 193, 240, 624, dev.stream)
+    assert np.array_equal(dev.host(gp), go[:, None] * np.arange(193, dtype=np.float32)[None, :, None, None])
