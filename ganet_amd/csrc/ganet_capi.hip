@@ -64,7 +64,9 @@ struct Options {
   std::atomic<int> gd_v{4};
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
-  std::atomic<int> lga_wave{2};   // LGA forward / data-backward: 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_wave{2};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
+  std::atomic<int> lga_vmcnt_safe{0};   // 1: the LDS-DMA kernels never count result stores when they wait for a staged plane (waits earlier than necessary)
   std::atomic<int> lga_segs{0};   // depth segments per tile for those kernels (0 = automatic)
   std::atomic<int> lga_split{1};  // automatic mode: unequal two-way depth split sized to the wave slots (LgaSeg::split_a)
   std::atomic<int> rowwave{1};      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
@@ -89,6 +91,8 @@ void load_env_options()
   geti("GANET_SGA_STREAMS", g_opt.streams);
   geti("GANET_LGA_WAVE", g_opt.lga_wave);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
+  geti("GANET_LGA_VMCNT_SAFE", g_opt.lga_vmcnt_safe);
+  geti("GANET_LGA_FG_WPS", g_opt.lga_fg_wps);
   geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
@@ -472,7 +476,7 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
 {
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  if (opts().lga_wave && W % 2 == 0 && ((uintptr_t)x & 7) == 0 && (i64)H * W < (1ll << 31)) {
+  if (opts().lga_wave && (opts().lga_wave == 3 || (W % 2 == 0 && ((uintptr_t)x & 7) == 0)) && (i64)H * W < (1ll << 30)) {
     LgaSeg sg;
     sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
     sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
@@ -494,15 +498,37 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
         sg.nseg = 1; sg.seg_len = D;          // nearly one item per slot already
       }
     }
+    if (opts().lga_wave == 3 && (i64)H * W < (1ll << 28)) {
+      // plane-pair kernel: segments start on even planes (32-bit byte offsets inside a plane pair)
+      if (sg.split_a > 0) sg.split_a &= ~1;
+      if (sg.split_a <= 0) {
+        sg.split_a = 0;
+        sg.seg_len = (sg.seg_len + 1) & ~1;
+        sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
+      }
+      const i64 items_pp = tiles * sg.nseg;
+      if constexpr (R <= 2) if (items_pp < (1ll << 31)) {
+        const bool relaxed = !opts().lga_vmcnt_safe;
+        if (transposed) {
+          if (relaxed) GA_LAUNCH((lga_apply_pp<R, true, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
+          else GA_LAUNCH((lga_apply_pp<R, true, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
+        } else {
+          if (relaxed) GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
+          else GA_LAUNCH((lga_apply_pp<R, false, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
+        }
+        if (getenv("GANET_TRACE_DISPATCH")) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d split=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg, sg.split_a);
+        return check_launch("lga apply (plane pairs)");
+      }
+    }
     const i64 items = tiles * sg.nseg;
     if constexpr (LgaDCfg<R>::OK) {
-      if (items < (1ll << 31) && opts().lga_wave == 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0) {
+      if (items < (1ll << 31) && opts().lga_wave >= 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0) {
         if (transposed) GA_LAUNCH((lga_apply_dma<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
         else GA_LAUNCH((lga_apply_dma<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
         return check_launch("lga apply (dma)");
       }
     }
-    if (items < (1ll << 31)) {
+    if (items < (1ll << 31) && W % 2 == 0 && ((uintptr_t)x & 7) == 0) {
       if (transposed) GA_LAUNCH((lga_apply_wave<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
       else GA_LAUNCH((lga_apply_wave<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
       return check_launch("lga apply (wave)");
@@ -520,8 +546,22 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
 {
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  if constexpr (R <= 2) {
+    if (opts().lga_wave == 3 && (i64)H * W < (1ll << 28)) {
+      LgaSeg sg;
+      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0;
+      const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+      if (items < (1ll << 31)) {
+        if (opts().lga_fg_wps == 2) GA_LAUNCH((lga_filter_grad_pp<R, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        else GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        return check_launch("lga filter grad (plane pairs)");
+      }
+    }
+  }
   if constexpr (LgaDCfg<R>::OK) {
-    if (opts().lga_wave == 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0 && (i64)H * W < (1ll << 31)) {
+    if (opts().lga_wave >= 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0 && (i64)H * W < (1ll << 31)) {
       LgaSeg sg;
       sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
       sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
@@ -587,7 +627,9 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
     if (strcmp(name, "GANET_SGA_GD_H")) g_opt.gd_v = value;
     if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
   } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : (value > 3 ? 3 : value);
+  else if (!strcmp(name, "GANET_LGA_VMCNT_SAFE")) g_opt.lga_vmcnt_safe = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_FG_WPS")) g_opt.lga_fg_wps = value == 2 ? 2 : 3;
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;

@@ -10,8 +10,10 @@
 // `input` is made current for the call (the reference relies on the Python-side torch.cuda.device_of).
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm presents its HIP devices as device type "cuda": the guard / stream accessors that accept such a device
+// are the *MasqueradingAsCUDA forms (the plain c10::hip::HIPGuard rejects it: "non-HIP DeviceType: cuda")
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "../../include/ganet_hip.h"
 
@@ -30,7 +32,7 @@ void check_all(const char *who, std::initializer_list<at::Tensor> ts)
 
 void check_rc(const char *who, int rc) { TORCH_CHECK(rc == GANET_OK, who, ": ", ganet_last_error()); }
 
-void *cur_stream() { return (void *)c10::hip::getCurrentHIPStream().stream(); }
+void *cur_stream() { return (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 float *p(const at::Tensor &t) { return t.data_ptr<float>(); }
 
@@ -46,7 +48,7 @@ int sga_cuda_forward(at::Tensor input, at::Tensor guidance_down, at::Tensor guid
                 "sga_cuda_forward: guidance must be [N,C,5,H,W]");
   for (const at::Tensor &t : {temp_out, output, mask})
     TORCH_CHECK(t.sizes() == input.sizes(), "sga_cuda_forward: temp_out / output / mask must have input's shape");
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   check_rc("sga_cuda_forward",
            ganet_sga_forward_compat(p(input), p(guidance_down), p(guidance_up), p(guidance_right), p(guidance_left),
                                     p(temp_out), p(output), p(mask), (int)input.size(0), (int)input.size(1),
@@ -69,7 +71,7 @@ int sga_cuda_backward(at::Tensor input, at::Tensor guidance_down, at::Tensor gui
     TORCH_CHECK(g.sizes() == guidance_down.sizes(), "sga_cuda_backward: guidance gradients must be [N,C,5,H,W]");
   TORCH_CHECK(max_idx.numel() == input.size(0) * input.size(1) * input.size(3) * input.size(4),
               "sga_cuda_backward: max_idx must be [N,C,H,W]");
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   check_rc("sga_cuda_backward",
            ganet_sga_backward_compat(p(input), p(guidance_down), p(guidance_up), p(guidance_right), p(guidance_left),
                                      p(temp_out), p(mask), p(max_idx), p(gradOutput), p(temp_grad), p(gradInput),
@@ -105,7 +107,7 @@ int lga_fwd(const char *who, at::Tensor input, at::Tensor filters, at::Tensor ou
   check_all(who, {input, filters, output});
   TORCH_CHECK(output.sizes() == input.sizes(), who, ": output must have input's shape");
   const LgaDims d = lga_dims(who, input, filters, radius, five_d);
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   // output is overwritten: equal to the reference's `+=` into the zero-filled buffer its caller hands over
   check_rc(who, ganet_lga_forward(p(input), p(filters), p(output), d.B, d.D, d.H, d.W, radius, cur_stream()));
   return 1;
@@ -119,7 +121,7 @@ int lga_bwd(const char *who, at::Tensor input, at::Tensor filters, at::Tensor gr
               ": gradOutput / gradInput must have input's shape");
   TORCH_CHECK(gradFilters.sizes() == filters.sizes(), who, ": gradFilters must have filters' shape");
   const LgaDims d = lga_dims(who, input, filters, radius, five_d);
-  c10::hip::HIPGuard guard(input.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
   // gradFilters accumulated into, gradInput overwritten (GANet_kernel.cu:1299-1322); gradInput may alias input
   check_rc(who, ganet_lga_backward(p(input), p(filters), p(gradOutput), p(gradInput), p(gradFilters), d.B, d.D, d.H, d.W,
                                    radius, 1, cur_stream()));

@@ -812,6 +812,589 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
   GA_VMCNT(0);      // no DMA may still be in flight when the wave's LDS is handed to the next workgroup
 }
 
+
+// ---- wave-autonomous forward / data-backward, PLANE-PAIR packing ----------------------------------------
+// lga_apply_dma packs its FMAs along the window's COLUMNS: a 5-wide window needs three aligned register pairs, one slot of
+// which carries a zero weight -- 45 v_pk_fma_f32 for 75 FMAs per plane (83 %), plus 15 further VALU per plane for the parity
+// bookkeeping and the slab reductions.  Here the two halves of a packed FMA are two consecutive PLANES at the same window
+// position.  The ring holds plane PAIRS, interleaved [row][col][2] in LDS, so ONE ds_read_b64 at any (8-byte aligned by
+// construction) window position returns X = (x[2m], x[2m+1]) and with E = (y[2m], y[2m+1]), O = (y[2m+1], y[2m+2]):
+//     E_m     += w( 0)[a,b] * X       (x[2m]   -> y[2m],   x[2m+1] -> y[2m+1])
+//     O_{m-1} += w(+1)[a,b] * X       (x[2m]   -> y[2m-1], x[2m+1] -> y[2m]  )
+//     O_m     += w(-1)[a,b] * X       (x[2m]   -> y[2m+1], x[2m+1] -> y[2m+2])
+// every packed FMA does two useful FMAs (75 per plane pair = 37.5 per plane), the weight is one plain dword broadcast to
+// both halves by op_sel (75 weight registers instead of 90, no parity, no dummy slot) and the window needs 25 LDS reads per
+// plane pair (12.5 per plane instead of 15).  After step m:  y[2m-1] = E_{m-1}.hi + O_{m-1}.lo,  y[2m] = E_m.lo + O_{m-1}.hi.
+// The interleaved layout is produced by the copy engine itself: global_load_lds_dword moves one dword per lane, lane l's
+// dword lands at slot + 4 l, and the lane's GLOBAL address is free -- lane l fetches plane (l & 1), cell (l >> 1) of the
+// halo'd tile (7 instructions per plane pair at R = 2).  Addresses are clamped into the image instead of masked (taps that
+// fall outside the image carry weight 0, so what is staged there does not matter as long as it is finite): no exec masks,
+// no ring clear.  Only a plane past the END of the volume (odd D: the last pair has one real plane) must read as zero; that
+// one pair zeroes its odd cells and loads the even lanes only.
+#ifndef LGAP_NR
+#define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
+#endif
+template <int R> struct LgaPCfg {
+  static constexpr int WS = 2 * R + 1;
+  static constexpr int TW2 = LGA_TW + 2 * R;               // no alignment padding: a cell is 8 bytes wherever it is
+  static constexpr int TH2 = LGAW_TH + 2 * R;
+  static constexpr int CELLS = TW2 * TH2;                  // cells per slot, two floats (planes) each
+  static constexpr int NDMA = (2 * CELLS + 63) / 64;       // copy instructions per plane pair
+  static constexpr int SLOT = NDMA * 64;                   // floats per slot: every lane of every copy owns a dword
+};
+
+// one 4-byte global -> LDS copy per lane, 64-bit per-lane address: lane l's dword lands at slot + 4 * l
+GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
+{
+#if defined(GA_HIPSIM)
+  slot[lane] = gsrc[0];
+#else
+  (void)lane;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
+}
+
+// acc += X * (w, w) with w = the LOW / HIGH half of the register pair W: op_sel picks the half for both results, so 2 n
+// loop-invariant weights live in n register pairs (written as fma2(X, mk2(w, w), acc) the optimiser hoists the splat out of
+// the loop as a 64-bit value per weight -- 150 registers at R = 2 -- and spills)
+template <int HALF> GA_DEV f2 fma2_bcast(f2 X, f2 W, f2 acc)
+{
+#if defined(GA_HIPSIM)
+  const float w = HALF ? W.y : W.x;
+  return fma2(X, mk2(w, w), acc);
+#else
+  if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(X), "v"(W));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(X), "v"(W));
+  return acc;
+#endif
+}
+
+// X * (w, w): starts an accumulator chain without a zero-initialised register pair
+template <int HALF> GA_DEV f2 mul2_bcast(f2 X, f2 W)
+{
+#if defined(GA_HIPSIM)
+  const float w = HALF ? W.y : W.x;
+  return mk2(X.x * w, X.y * w);
+#else
+  f2 r;
+  if (HALF) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(X), "v"(W));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(X), "v"(W));
+  return r;
+#endif
+}
+
+// all ND copies of one plane pair: copy k moves lane l's dword from base + off[k] (bytes) to slot + 256 k + 4 l.  One M0
+// save / restore around the batch (M0 = LDS base of the copy; a write to M0 needs one wait state before the copy that
+// uses it).  Scalar base + 32-bit lane offset: the offsets are the same for every pair, only the base moves.
+#define GA_PP_COPY(n) "s_nop 0\n\tglobal_load_lds_dword %" #n ", %2\n\ts_add_u32 m0, m0, 0x100\n\t"
+template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&o)[ND], float *slot, int lane)
+{
+#if defined(GA_HIPSIM)
+  for (int k = 0; k < ND; k++) slot[k * 64 + lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k]);
+#else
+  (void)lane;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  static_assert(ND == 5 || ND == 7 || ND == 10, "copy batch written out for R = 1, 2, 3");
+  if constexpr (ND == 5)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]) : "memory", "scc");
+  else if constexpr (ND == 7)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
+                 GA_PP_COPY(8) GA_PP_COPY(9) "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]) : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
+                 GA_PP_COPY(8) GA_PP_COPY(9) GA_PP_COPY(10) GA_PP_COPY(11) GA_PP_COPY(12) "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]),
+                   "v"(o[8]), "v"(o[9]) : "memory", "scc");
+#endif
+}
+
+// weights of one pixel for the plane-pair kernels: tap t = (dd * WS + a) * WS + b in half (t & 1) of register pair t >> 1,
+// zero where the tap leaves the image; cmid / sin_m / sin_p as in lga_gather_weights (centre coefficient of the spatially
+// replaced taps, in-range sums of the two outer depth slabs).  One depth slab at a time (scheduling fence in between): left
+// alone, the compiler issues all 125 loads of the transposed gather first and spills their destinations.
+template <int R, bool TRANSPOSED, bool CHECK>
+GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, int ic, int jc,
+                             f2 (&wq)[(3 * (2 * R + 1) * (2 * R + 1) + 1) / 2], float &cmid, float &sin_m, float &sin_p)
+{
+  constexpr int WS = 2 * R + 1, K = WS * WS, NT = 3 * K;
+  // every address = (uniform tap-plane pointer) + (32-bit per-lane pixel offset): scalar base + one offset register per
+  // distinct neighbour instead of a 64-bit address per load
+  const unsigned pix32 = (unsigned)(ic * geo.W + jc);
+  auto tap = [&](int t) -> float {
+    const int dd = t / K, a = (t % K) / WS - R, bb = t % WS - R;
+    bool ok = true;
+    if (CHECK) {
+      const int i2 = ic + a, j2 = jc + bb;
+      ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
+    }
+    float own = 0.f;
+    if (CHECK || !TRANSPOSED || dd != 1) own = (fb + (i64)t * geo.HW)[pix32];   // interior gX needs own taps only for the d-edge sums
+    float wv = own;
+    if (TRANSPOSED) {
+      // unconditional load, value masked below (a load under a condition costs an s_waitcnt vmcnt(0) each)
+      const int tf = (2 - dd) * K + (-a + R) * WS + (-bb + R);
+      const int noff = ok ? a * geo.W + bb : 0;
+      wv = (fb + (i64)tf * geo.HW)[(unsigned)((int)pix32 + noff)];
+    }
+    const int okm = ok ? -1 : 0;
+    cmid += i2f(f2i(own) & ~okm);
+    if (dd == 0) sin_m += i2f(f2i(own) & okm);
+    if (dd == 2) sin_p += i2f(f2i(own) & okm);
+    return i2f(f2i(wv) & okm);
+  };
+#pragma unroll
+  for (int t = 0; t < NT; t += 2) {
+    const float lo = tap(t);
+    const float hi = t + 1 < NT ? tap(t + 1) : 0.f;
+    wq[t >> 1] = mk2(lo, hi);
+    if ((t + 2) % K < 2) GA_SCHED_FENCE();            // (about once per depth slab)
+  }
+}
+
+template <int R, bool TRANSPOSED, bool RELAXED_WAIT>
+__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
+lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
+             LgaGeom geo, LgaSeg sg)
+{
+  typedef LgaPCfg<R> PC;
+  constexpr int WS = PC::WS, K = WS * WS, NR = LGAP_NR, P = NR - 1, ND = PC::NDMA;
+  __shared__ __attribute__((aligned(16))) float ring[NR * PC::SLOT];
+  const int lane = threadIdx.x;                       // blockDim.x == 64
+  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
+  int bx, by, b, d_lo, d_hi;
+  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);   // the launcher makes every segment start on an even plane
+  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
+  const int i = ty0 + ty, j = tx0 + tx;
+  const bool inb = i < geo.H && j < geo.W;
+  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
+  const float *xb = x + (i64)b * geo.D * geo.HW;
+  const float *fb = f + (i64)b * 3 * K * geo.HW;
+  float *yb = y + (i64)b * geo.D * geo.HW;
+  const i64 pix = (i64)ic * geo.W + jc;
+  if (d_lo >= geo.D) return;
+
+  // output planes [d_lo, d_hi) need input planes [d_lo - 1, min(d_hi, D - 1)]: pairs m_lo .. m_hi
+  const int D = geo.D;
+  const int p_hi = d_hi < D ? d_hi : D - 1;           // last input plane needed
+  const int m_lo = d_lo > 0 ? (d_lo - 1) >> 1 : 0;
+  const int m_hi = p_hi >> 1;
+  const int npair = m_hi - m_lo + 1;
+
+  // per-lane byte offset of every copy of a pair (clamped into the image), relative to the pair's even plane
+  unsigned goff[ND];
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const int e = k * 64 + lane;
+    int cell = e >> 1;
+    cell = cell < PC::CELLS ? cell : PC::CELLS - 1;   // (padding cells of the last copy: any valid address)
+    const int r = cell / PC::TW2, c = cell - r * PC::TW2;
+    int i2 = ty0 + r - R, j2 = tx0 + c - R;
+    i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
+    j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
+    goff[k] = 4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2));      // (launcher: 2 HW floats < 2^30)
+  }
+  const float *gbase = xb + (i64)(2 * m_lo) * geo.HW;      // uniform: even plane of the next pair to request
+  // pairs are requested in order q = 0, 1, 2, ... (relative to m_lo); past the last one the last is requested again so that
+  // the operation count per step stays fixed.  half: the pair's odd plane does not exist (2 m + 1 == D).
+  int dma_slot = 0;
+  auto dma = [&](int q) {
+    const int qq = q < npair ? q : npair - 1;
+    const bool half = 2 * (m_lo + qq) + 1 >= D;       // uniform
+    float *slot = ring + dma_slot * PC::SLOT;
+    if (half) {
+      if (q < npair) {                                // the one real half pair: its odd cells must read as zero
+        if (lane & 1) {
+#pragma unroll
+          for (int k = 0; k < ND; k++) slot[k * 64 + lane] = 0.f;
+        }
+        GA_LGKMCNT0();
+        GA_WAVE_SYNC();
+      }
+      if ((lane & 1) == 0) lga_dma4p_all<ND>(gbase, goff, slot, lane);
+    } else {
+      lga_dma4p_all<ND>(gbase, goff, slot, lane);
+    }
+    if (q + 1 < npair) gbase += 2 * geo.HW;
+    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
+  };
+  for (int q = 0; q < P; q++) dma(q);
+
+  // weights: tap t = (dd * WS + a) * WS + b lives in half (t & 1) of register pair t >> 1
+  constexpr int NT = 3 * K, NWP = (NT + 1) / 2;
+  f2 wq[NWP];
+  float cmid = 0.f, sin_m = 0.f, sin_p = 0.f;
+  const bool interior = ty0 >= R && ty0 + LGAW_TH + R <= geo.H && tx0 >= R && tx0 + LGA_TW + R <= geo.W;
+  if (interior)
+    lga_gather_pairs<R, TRANSPOSED, false>(fb, geo, ic, jc, wq, cmid, sin_m, sin_p);
+  else
+    lga_gather_pairs<R, TRANSPOSED, true>(fb, geo, ic, jc, wq, cmid, sin_m, sin_p);
+
+  // window rows stream through a register ring with LA rows of LDS look-ahead (rows of the NEXT pair for the last LA rows)
+  constexpr int LA = LGAW_LA;
+  static_assert(WS > LA, "look-ahead must stay within the next pair");
+  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + 2 * (ty * PC::TW2 + tx);
+  f2 vrow[LA + 1][WS];
+  GA_VMCNT(0);                                             // everything requested so far has landed (pair 0 is what is needed;
+  GA_WAVE_SYNC();                                          // a counted wait here would be fooled by a prologue spill)
+#pragma unroll
+  for (int s0 = 0; s0 < LA; s0++) {
+#pragma unroll
+    for (int bb = 0; bb < WS; bb++) vrow[s0][bb] = lds_read_b64(lbase + 2 * (s0 * PC::TW2 + bb));
+  }
+
+  f2 o_prev = mk2(0.f, 0.f);                     // O_{m-1} so far: (y[2m-1], y[2m]) contributions of pair m-1
+  float e_hi_prev = 0.f;                         // E_{m-1}.hi
+  float xc_prev = 0.f;                           // centre sample of plane 2m-1
+  int slot_c = 0;
+  // the row ring has LA + 1 entries and a pair has WS rows: unroll U pairs so that the ring closes (U * WS % (LA + 1) == 0)
+  constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
+  constexpr int NSTEP = U * WS;
+  static_assert(NSTEP % (LA + 1) == 0, "row ring must close");
+  for (int q0 = 0; q0 < npair; q0 += U) {
+    f2 eA, eB, pA, pB, cA, cB;                   // E_m, O_{m-1} increment, O_m: two chains each
+    f2 xc2 = mk2(0.f, 0.f);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      const int u = st / WS, a = st % WS;
+      const int q = q0 + u;
+      const int m = m_lo + q;
+      if (a == 0) dma(q + P);                    // overwrites the slot of pair q - 1, whose rows have all been consumed
+      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
+      const lds_cptr cur = lbase + slot_c * PC::SLOT, nxt = lbase + slot_n * PC::SLOT;
+      if (a == WS - LA) {
+        // pair q + 1 must have landed.  After its copies came those of P - 1 further pairs and, once the march is under way,
+        // the two y stores of each of the P - 1 steps in between (every step from the second on issues exactly two: some
+        // lane of a tile is always inside the image).  RELAXED_WAIT = false ignores the stores (waits earlier than needed).
+        int qq = q;
+        GA_OPAQUE_S(qq);
+        if (RELAXED_WAIT && qq >= P + 1 && qq + 1 < npair && m_lo + qq - P >= (d_lo >> 1) + 1) GA_VMCNT((ND + 2) * (P - 1));
+        else GA_VMCNT(ND * (P - 1));
+        GA_WAVE_SYNC();
+      }
+      {
+        const int t = a + LA;
+        const lds_cptr src = t < WS ? cur + 2 * t * PC::TW2 : nxt + 2 * (t - WS) * PC::TW2;
+#pragma unroll
+        for (int bb = 0; bb < WS; bb++) vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
+      }
+      GA_SCHED_FENCE();
+#pragma unroll
+      for (int bb = 0; bb < WS; bb++) {
+        const f2 X = vrow[st % (LA + 1)][bb];
+        const int tm = (0 * WS + a) * WS + bb, t0 = (1 * WS + a) * WS + bb, tp = (2 * WS + a) * WS + bb;   // slabs -1, 0, +1
+        const int n = a * WS + bb;                        // taps alternate between two chains per accumulator
+#define GA_PP_ACC(acc, t)                                                                                    \
+        acc = n < 2 ? ((t & 1) ? mul2_bcast<1>(X, wq[t >> 1]) : mul2_bcast<0>(X, wq[t >> 1]))               \
+                    : ((t & 1) ? fma2_bcast<1>(X, wq[t >> 1], acc) : fma2_bcast<0>(X, wq[t >> 1], acc))
+        if (n & 1) { GA_PP_ACC(eB, t0); GA_PP_ACC(pB, tp); GA_PP_ACC(cB, tm); }
+        else { GA_PP_ACC(eA, t0); GA_PP_ACC(pA, tp); GA_PP_ACC(cA, tm); }
+#undef GA_PP_ACC
+        GA_SCHED_FENCE();
+        if (a == R && bb == R) xc2 = X;
+      }
+      if (a == WS - 1) {
+        GA_KEEP_F2(eA); GA_KEEP_F2(eB); GA_KEEP_F2(pA); GA_KEEP_F2(pB); GA_KEEP_F2(cA); GA_KEEP_F2(cB);
+        const bool live = q < npair;                       // uniform
+        const f2 e = add2(eA, eB);
+        const f2 o = add2(o_prev, add2(pA, pB));           // O_{m-1} complete
+        const int d1 = 2 * m - 1, d2 = 2 * m;
+        if (live && d1 >= d_lo && d1 < d_hi) {
+          float cc = cmid;
+          if (d1 == D - 1) cc += sin_p;                    // (d1 is odd: never plane 0)
+          const float r = fmaf(xc_prev, cc, e_hi_prev + o.x);
+          if (inb) yb[(i64)d1 * geo.HW + pix] = r;
+        }
+        if (live && d2 >= d_lo && d2 < d_hi) {
+          float cc = cmid;
+          if (d2 == 0) cc += sin_m;
+          if (d2 == D - 1) cc += sin_p;
+          const float r = fmaf(xc2.x, cc, e.x + o.y);
+          if (inb) yb[(i64)d2 * geo.HW + pix] = r;
+        }
+        if (live) {
+          o_prev = add2(cA, cB);
+          e_hi_prev = e.y;
+          xc_prev = xc2.y;
+        }
+        slot_c = slot_n;
+      }
+    }
+  }
+  {
+    // even D at the end of the volume: plane D - 1 = 2 m_hi + 1 has no later pair to be completed by
+    const int d1 = 2 * m_hi + 1;
+    if (d1 >= d_lo && d1 < d_hi && d1 < D) {
+      float cc = cmid;
+      if (d1 == D - 1) cc += sin_p;
+      const float r = fmaf(xc_prev, cc, e_hi_prev + o_prev.x);
+      if (inb) yb[(i64)d1 * geo.HW + pix] = r;
+    }
+  }
+  GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
+}
+
+// one 4-byte global -> LDS copy per lane, scalar base + 32-bit lane offset: lane l's dword lands at slot + 4 * l
+GA_DEV void lga_dma4s(const float *base, unsigned off, float *slot, int lane)
+{
+#if defined(GA_HIPSIM)
+  slot[lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off);
+#else
+  (void)lane;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %3, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "s"(base), "v"(off) : "memory");
+#endif
+}
+
+// acc += (x, x) * G with x = the LOW / HIGH half of X (op_sel on the first operand)
+template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
+{
+#if defined(GA_HIPSIM)
+  const float x = HALF ? X.y : X.x;
+  return fma2(mk2(x, x), G, acc);
+#else
+  if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(X), "v"(G));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(X), "v"(G));
+  return acc;
+#endif
+}
+
+// ---- filter backward, PLANE-PAIR packing -------------------------------------------------------------------
+// Same staging as lga_apply_pp (plane pairs X = (x[2m], x[2m+1]) interleaved in LDS, one ds_read_b64 per window position),
+// the lane's own gy values through a second ring (one dword copy per plane, [plane][lane]).  With g_k = gy[k] of the pixel:
+//     P[a,b] = (gf(-1), gf(0))[a,b]     += (x[2m],   x[2m]  ) * (g_{2m+1}, g_{2m}  )
+//                                       += (x[2m+1], x[2m+1]) * (g_{2m+2}, g_{2m+1})
+//     Q[a,b] = gf(+1)[a,b] as (lo, hi)  += (x[2m],   x[2m+1]) * (g_{2m-1}, g_{2m}  )
+// 75 packed FMAs per plane PAIR, all useful (the column-packed kernel needs 45 per plane), 100 accumulator registers
+// (90 there), 25 LDS window reads per pair.  Copies per step, in this order: gy(2q+1), gy(2q+2), then the ND copies of x
+// pair q -- so once x pair q has landed, gy up to plane 2q+2 has too.
+// WPS = waves per SIMD the register budget is set for, LA = window rows of LDS look-ahead.  The explicit s_waitcnt vmcnt(n)
+// bookkeeping of the march is only valid while the compiler adds NO vector-memory operation of its own to the loop -- a
+// register spill is one (scratch_load / scratch_store count in vmcnt) -- so the (WPS, LA) pairs offered by the launcher are
+// the ones scripts/isa_lint.py finds spill-free inside the loop: (3, 0) and (2, 2) at R = 2.
+template <int R, int WPS, int LA_>
+__global__ void __launch_bounds__(64, WPS)
+lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
+                   LgaGeom geo, LgaSeg sg, int accumulate)
+{
+  typedef LgaPCfg<R> PC;
+  constexpr int WS = PC::WS, K = WS * WS, NR = LGAP_NR, P = NR - 1, ND = PC::NDMA, NGS = 2 * P + 4, VPS = ND + 2;
+  static_assert(VPS * P < 64, "vmcnt immediate");
+  __shared__ __attribute__((aligned(16))) float ring[NR * PC::SLOT];
+  __shared__ __attribute__((aligned(16))) float gring[NGS * 64];
+  __shared__ unsigned goff_lds[ND * 64];               // per-lane byte offsets of the x copies, parked here between steps
+  const int lane = threadIdx.x;                       // blockDim.x == 64
+  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
+  int item = xcd_remap(blockIdx.x, gridDim.x);        // tiles along a row first; each XCD a contiguous band
+  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
+  const int by = item % sg.tiles_y;
+  const int b = item / sg.tiles_y;
+  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
+  const int i = ty0 + ty, j = tx0 + tx;
+  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
+  const float *xb = x + (i64)b * geo.D * geo.HW;
+  const float *gyb = gy + (i64)b * geo.D * geo.HW;
+  const i64 pix = (i64)ic * geo.W + jc;
+  const int D = geo.D;
+  const int npair = (D + 1) >> 1;
+
+  unsigned goff[ND];
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    const int e = k * 64 + lane;
+    int cell = e >> 1;
+    cell = cell < PC::CELLS ? cell : PC::CELLS - 1;
+    const int r = cell / PC::TW2, c = cell - r * PC::TW2;
+    int i2 = ty0 + r - R, j2 = tx0 + c - R;
+    i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
+    j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
+    goff[k] = 4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2));
+    goff_lds[k * 64 + lane] = goff[k];
+  }
+  const unsigned gyoff = 4u * (unsigned)pix;
+  const float *xsrc = xb;                              // uniform: even plane of the next x pair to request
+  const float *gysrc = gyb;                            // uniform: next gy plane to request
+  int dma_slot = 0, g_slot = 0;
+  auto dma_x = [&](int q, bool reload) {               // x pair q (past the end: the last pair again, fixed operation count)
+    if (reload) {
+#pragma unroll
+      for (int k = 0; k < ND; k++) goff[k] = goff_lds[k * 64 + lane];
+    }
+    const int qq = q < npair ? q : npair - 1;
+    const bool half = 2 * qq + 1 >= D;                 // uniform
+    float *slot = ring + dma_slot * PC::SLOT;
+    if (half) {
+      if (q < npair) {
+        if (lane & 1) {
+#pragma unroll
+          for (int k = 0; k < ND; k++) slot[k * 64 + lane] = 0.f;
+        }
+        GA_LGKMCNT0();
+        GA_WAVE_SYNC();
+      }
+      if ((lane & 1) == 0) lga_dma4p_all<ND>(xsrc, goff, slot, lane);
+    } else {
+      lga_dma4p_all<ND>(xsrc, goff, slot, lane);
+    }
+    if (q + 1 < npair) xsrc += 2 * geo.HW;
+    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
+  };
+  auto dma_g = [&](int k) {                            // gy plane k (clamped; its value is masked where k >= D)
+    lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
+    if (k + 1 < D) gysrc += geo.HW;
+    g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
+  };
+  // gy ring: plane k lives in slot k % NGS
+  dma_g(0);
+  for (int q = 0; q < P; q++) { dma_g(2 * q + 1); dma_g(2 * q + 2); dma_x(q, false); }
+
+  f2 Pq[WS][WS], Qq[WS][WS];
+#pragma unroll
+  for (int a = 0; a < WS; a++) {
+#pragma unroll
+    for (int bb = 0; bb < WS; bb++) Pq[a][bb] = Qq[a][bb] = mk2(0.f, 0.f);
+  }
+  float gc = 0.f;                 // sum_d gy[d] * x[d][centre]
+  float e_lo = 0.f, e_hi = 0.f;   // gy[0]*x[0][c], gy[D-1]*x[D-1][c]
+
+  constexpr int LA = LA_;
+  static_assert(WS > LA, "look-ahead must stay within the next pair");
+  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + 2 * (ty * PC::TW2 + tx);
+  const lds_cptr gbase = GA_LDS_CPTR(&gring[0]) + lane;
+  f2 vrow[LA + 1][WS];
+  GA_VMCNT(0);                                             // everything requested so far has landed (pair 0 is what is needed;
+  GA_WAVE_SYNC();                                          // a counted wait here would be fooled by a prologue spill)
+#pragma unroll
+  for (int s0 = 0; s0 < LA; s0++) {
+#pragma unroll
+    for (int bb = 0; bb < WS; bb++) vrow[s0][bb] = lds_read_b64(lbase + 2 * (s0 * PC::TW2 + bb));
+  }
+  int slot_c = 0;
+  int gs = 0;                                    // gy ring slot of plane 2q
+  constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
+  constexpr int NSTEP = U * WS;
+  for (int q0 = 0; q0 < npair; q0 += U) {
+    f2 Ga = mk2(0.f, 0.f), Gb = mk2(0.f, 0.f), Gc = mk2(0.f, 0.f);
+    f2 xc2 = mk2(0.f, 0.f);
+#pragma unroll
+    for (int st = 0; st < NSTEP; st++) {
+      const int u = st / WS, a = st % WS;
+      const int q = q0 + u;
+      const bool live = q < npair;                         // uniform
+      if (a == 0) {
+        // the slots these overwrite held x pair q - 1 and gy planes 2q - 3, 2q - 2: all consumed (the lanes of a wave run in
+        // lockstep; the wave barrier is a compiler fence here and a real one in the CPU emulator)
+        GA_WAVE_SYNC();
+        dma_g(2 * (q + P) + 1);
+        dma_g(2 * (q + P) + 2);
+        dma_x(q + P, true);
+      }
+      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
+      const lds_cptr cur = lbase + slot_c * PC::SLOT, nxt = lbase + slot_n * PC::SLOT;
+      if ((a + LA) % WS == 0) {
+        // the rows read from here on belong to x pair q + 1 (LA > 0) or q (LA = 0): it -- and with it gy up to two planes
+        // past it -- must have landed.  After its last copy came VPS operations for each later pair up to q + P.
+        GA_VMCNT(VPS * (P - (LA > 0 ? 1 : 0)));
+        GA_WAVE_SYNC();
+      }
+      if (a == 0) {
+        // gy[2q-1 .. 2q+2] of the own pixel (0 outside [0, D)); all landed: they precede x pair q in issue order
+        const int s_m1 = gs == 0 ? NGS - 1 : gs - 1, s_p1 = gs + 1 == NGS ? 0 : gs + 1, s_p2 = s_p1 + 1 == NGS ? 0 : s_p1 + 1;
+        const float gm1v = gbase[s_m1 * 64];
+        const float gm1 = (q > 0 && live) ? gm1v : 0.f;
+        const float g0v = gbase[gs * 64];
+        const float g1v = gbase[s_p1 * 64], g2v = gbase[s_p2 * 64];
+        const float g1 = 2 * q + 1 < D ? g1v : 0.f;
+        const float g2 = 2 * q + 2 < D ? g2v : 0.f;
+        const float g0 = live ? g0v : 0.f;                 // a step past the last pair runs on zero multipliers (no branch
+                                                           // around the FMAs: the 100 accumulators would meet at a merge)
+        Ga = mk2(g1, g0);
+        Gb = mk2(g2, g1);
+        Gc = mk2(gm1, g0);
+      }
+      {
+        const int t = a + LA;
+        const lds_cptr src = t < WS ? cur + 2 * t * PC::TW2 : nxt + 2 * (t - WS) * PC::TW2;
+#pragma unroll
+        for (int bb = 0; bb < WS; bb++) vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
+      }
+      GA_SCHED_FENCE();
+#pragma unroll
+      for (int bb = 0; bb < WS; bb++) {
+        const f2 X = vrow[st % (LA + 1)][bb];
+        Pq[a][bb] = fma2(mk2(X.x, X.x), Ga, Pq[a][bb]);     // (a splat of a freshly loaded value: the compiler's own op_sel)
+        Qq[a][bb] = fma2(X, Gc, Qq[a][bb]);
+        if (a == R && bb == R) xc2 = X;
+      }
+#pragma unroll
+      for (int bb = 0; bb < WS; bb++) {
+        const f2 X = vrow[st % (LA + 1)][bb];
+        Pq[a][bb] = fma2(mk2(X.y, X.y), Gb, Pq[a][bb]);
+      }
+      GA_SCHED_FENCE();
+      if (a == WS - 1) {
+        {
+          // Ga = (g[2q+1], g[2q]) (zeros past the end), centre samples xc2 = (x[2q][c], x[2q+1][c])
+          const float e0 = Ga.y * xc2.x, e1 = Ga.x * xc2.y;
+          gc += e0 + e1;
+          if (q == 0) e_lo = e0;
+          if (2 * q == D - 1) e_hi = e0;
+          if (2 * q + 1 == D - 1) e_hi = e1;
+        }
+        slot_c = slot_n;
+        gs = gs + 2 >= NGS ? gs + 2 - NGS : gs + 2;
+      }
+    }
+  }
+  GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
+
+  // Everything the write-out needs about the pixel is recomputed here from an opaque copy of the lane id: kept live
+  // across the march it costs ~10 of the registers the 4 K accumulators leave (the kernel spilled in its inner loop).
+  {
+    int lane2 = threadIdx.x;
+#if !defined(GA_HIPSIM)
+    asm volatile("" : "+v"(lane2));
+#endif
+    const int i_ = ty0 + lane2 / LGA_TW, j_ = tx0 + lane2 % LGA_TW;
+    if (i_ < geo.H && j_ < geo.W) {
+      float *gfp = gf + (i64)b * 3 * K * geo.HW + (i64)i_ * geo.W + j_;
+#pragma unroll
+      for (int dd = 0; dd < 3; dd++) {
+        // accumulate mode: the K old values of this depth slab are loaded together, then added and stored
+        float old[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) old[k] = 0.f;
+        if (accumulate) {
+#pragma unroll
+          for (int k = 0; k < K; k++) old[k] = gfp[(i64)(dd * K + k) * geo.HW];
+        }
+#pragma unroll
+        for (int a = -R; a <= R; a++) {
+#pragma unroll
+          for (int bb = -R; bb <= R; bb++) {
+            const int t = dd * K + (a + R) * WS + (bb + R);
+            const int i2 = i_ + a, j2 = j_ + bb;
+            const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
+            float r;
+            if (dd == 0) r = Pq[a + R][bb + R].x + e_lo;
+            else if (dd == 1) r = Pq[a + R][bb + R].y;
+            else r = Qq[a + R][bb + R].x + Qq[a + R][bb + R].y + e_hi;
+            if (!ok) r = gc;
+            gfp[(i64)t * geo.HW] = old[(a + R) * WS + (bb + R)] + r;
+          }
+        }
+      }
+    }
+  }
+}
+
 // one 4-byte global -> LDS copy per lane: lane l's dword lands at slot + 4 * l
 GA_DEV void lga_dma4(const float *gsrc, float *slot, int lane)
 {

@@ -19,6 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from harness.miopen_env import use_repo_miopen_cache  # noqa: E402
+
+use_repo_miopen_cache()            # before torch loads MIOpen
+
 import torch  # noqa: E402
 
 from ganet_amd import dist as gdist  # noqa: E402
@@ -38,7 +42,10 @@ def parse(argv=None):
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--kitti", type=int, default=1)
     ap.add_argument("--sync_bn", action="store_true")
+    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
+                    help="MIOpen immediate mode (heuristic solver choice) instead of timing its solvers per shape")
     ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--kernel_share", action="store_true", help="add the per-group device-time table (torch.profiler over 2 extra steps, rank 0)")
     ap.add_argument("--resume", default="")
     ap.add_argument("--save", default="")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
@@ -54,6 +61,7 @@ def run(args, hook=None):
     else:
         dev = torch.device("cuda", ctx.local_rank)
         torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)     # MIOpen find mode (harness/miopen_env.py)
     torch.manual_seed(123)                      # same initial weights on every rank (DDP broadcasts rank 0's anyway)
     model = steps.build_model(args.model, args.max_disp, dev, sync_bn=args.sync_bn and ctx.world_size > 1,
                               ddp=ctx.world_size > 1, local_rank=ctx.local_rank, hook=hook)
@@ -80,19 +88,23 @@ def run(args, hook=None):
             losses.append(float(loss))
 
     elapsed = gdist.timed_region(ctx, timed, sync=sync)
+    share = None
+    if args.kernel_share and ctx.rank == 0 and not cpu and ctx.world_size == 1:
+        from harness.kernel_share import profile_passes
+        share = profile_passes(lambda: steps.train_step(model, opt, args.model, left, right, target, args.max_disp, crit), 2)
     if args.save and ctx.rank == 0:
         steps.save_checkpoint(args.save, model, opt, epoch0 + 1)
     line = {"what": "training step, reference model on the drop-in ops", "model": args.model, "n_gpus": ctx.world_size,
             "per_gpu_batch": args.batch, "crop": [args.crop_height, args.crop_width], "max_disp": args.max_disp,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "samples_per_sec": round(ctx.world_size * args.batch * args.steps / elapsed, 3),
-            "steps": args.steps, "warmup": args.warmup, "sync_bn": bool(args.sync_bn and ctx.world_size > 1),
+            "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find), "sync_bn": bool(args.sync_bn and ctx.world_size > 1),
             "ops": "ganet_amd.modules.fused" if args.fused else "drop-in call forms (libs/)",
             "grad_allreduce": "DistributedDataParallel (RCCL)" if ctx.world_size > 1 and not cpu else
                               ("DistributedDataParallel (gloo)" if ctx.world_size > 1 else "none (1 rank)"),
             "peak_mem_GB": None if cpu else round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
             "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)], "dtype": "f32",
-            "data": "synthetic", "weights": "random init" if not args.resume else args.resume}
+            "data": "synthetic", "weights": "random init" if not args.resume else args.resume, "kernel_share": share}
     gdist.finish(ctx)
     if ctx.rank == 0:
         print(json.dumps(line))

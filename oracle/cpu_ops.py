@@ -15,11 +15,12 @@ from .fused_ref import disparity_regression
 
 
 def _np(t):
-    return np.ascontiguousarray(t.detach().numpy(), dtype=np.float32)
+    return np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
 
 
-def _t(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+def _t(a, like=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t if like is None else t.to(like.device)        # device tensors make a host round trip (hybrid test arm)
 
 
 class OracleSga(torch.autograd.Function):
@@ -28,13 +29,13 @@ class OracleSga(torch.autograd.Function):
         out, tmp, mask = ora.sga_forward(_np(x), _np(g0), _np(g1), _np(g2), _np(g3))
         ctx.ora, ctx.tmp, ctx.mask = ora, tmp, mask
         ctx.save_for_backward(x, g0, g1, g2, g3)
-        return _t(out)
+        return _t(out, x)
 
     @staticmethod
     def backward(ctx, go):
         x, g0, g1, g2, g3 = ctx.saved_tensors
         grads = ctx.ora.sga_backward(_np(x), _np(g0), _np(g1), _np(g2), _np(g3), ctx.tmp, ctx.mask, _np(go))
-        return (None, *[_t(g) for g in grads])
+        return (None, *[_t(g, go) for g in grads])
 
 
 class OracleLgaChain(torch.autograd.Function):
@@ -43,13 +44,13 @@ class OracleLgaChain(torch.autograd.Function):
         y, ins = ora.lga_chain_forward(_np(x), _np(f), radius, passes)
         ctx.ora, ctx.radius, ctx.ins = ora, radius, ins
         ctx.save_for_backward(f)
-        return _t(y)
+        return _t(y, x)
 
     @staticmethod
     def backward(ctx, gy):
         f, = ctx.saved_tensors
         gx, gf = ctx.ora.lga_chain_backward(ctx.ins, _np(f), _np(gy), ctx.radius)
-        return None, _t(gx), _t(gf), None, None
+        return None, _t(gx, gy), _t(gf, gy), None, None
 
 
 def cost_volume(x, y, ndisp):
@@ -71,7 +72,9 @@ _LGA_PASSES = {"LGA": 1, "LGA2": 2, "LGA3": 3, "LGA3D": 1, "LGA3D2": 2, "LGA3D3"
 
 def route_cpu_through_oracle(model, ora):
     """Rebinds forward of every GA-op module instance in `model` (matched by the reference's class names, so it works
-    for this repo's modules and for the reference's own) to the oracle-backed CPU forms above.  Returns the count."""
+    for this repo's modules and for the reference's own) to the oracle-backed CPU forms above.  Returns the count.
+    Works on a model that lives on the GPU too (each op then copies its tensors to the host and back): the hybrid arm of
+    tests/test_gpu_model.py, which isolates the GA ops from PyTorch's own CPU-vs-GPU arithmetic differences."""
     n = 0
     for m in model.modules():
         kind = type(m).__name__

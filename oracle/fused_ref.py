@@ -28,7 +28,7 @@ def lga_filters(g):
 
 def disparity_regression(x, maxdisp):
     """libs/GANet/modules/GANet.py:142-147 without the hard-coded .cuda()"""
-    disp = torch.arange(0, maxdisp + 1, dtype=x.dtype).reshape(1, maxdisp + 1, 1, 1)
+    disp = torch.arange(0, maxdisp + 1, dtype=x.dtype, device=x.device).reshape(1, maxdisp + 1, 1, 1)
     disp = disp.repeat(x.size(0), 1, x.size(2), x.size(3))
     return torch.sum(x * disp, 1)
 

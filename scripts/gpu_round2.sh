@@ -1,0 +1,73 @@
+#!/bin/bash
+# One GPU session of round 2.  gpurun --timeout N -- 'bash scripts/gpu_round2.sh <tag> [parts]'
+#   parts: any of  ubench tests smoke bench prof model modelprof  (default: all but ubench/modelprof)
+# Everything worth keeping goes to gpurun_out/<tag>/ (merged back into the dev container).
+TAG=${1:-r2}
+PARTS=${2:-"tests smoke bench prof model"}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+# MIOpen: no gfx950 find-db / kernel-db ships with the image; keep what this box compiles and bring back what an
+# earlier call compiled (miopen_cache/ travels with the snapshot, gpurun_out/ does not)
+mkdir -p /tmp/miopen/db /tmp/miopen/cache
+[ -d $ROOT/miopen_cache ] && cp -r $ROOT/miopen_cache/. /tmp/miopen/ 2>/dev/null
+export MIOPEN_USER_DB_PATH=/tmp/miopen/db MIOPEN_CUSTOM_CACHE_DIR=/tmp/miopen/cache
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+{
+  echo "== host"; nproc; lscpu | grep -m1 'Model name'; rocminfo | grep -m3 -E 'Marketing Name|gfx'
+} > $OUT/host.txt 2>&1
+if has ubench; then
+  echo "== ubench"
+  for b in scripts/ubench/*.bin; do [ -x $b ] && { echo "-- $b"; timeout 120 $b; } ; done > $OUT/ubench.txt 2>&1
+  tail -30 $OUT/ubench.txt
+fi
+if has tests; then
+  echo "== pytest -m gpu (ops)"
+  SECONDS=0
+  timeout 1500 python -m pytest tests -m gpu -x -q -s --deselect tests/test_gpu_model.py > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$? (${SECONDS}s)"; tail -25 $OUT/pytest_gpu.txt
+fi
+if has smoke; then
+  echo "== smoke"
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.txt
+fi
+if has bench; then
+  echo "== bench"
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
+fi
+if has prof; then
+  echo "== rocprof kernel trace (bench)"
+  ( cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" )
+  find $OUT/prof -name '*kernel_stats*' | head -1 | xargs -r head -16
+fi
+if has ablga; then
+  echo "== LGA kernel families A/B"
+  timeout 400 python scripts/ab_lga.py > $OUT/ab_lga.txt 2>&1; echo "ab_lga rc=$?"; grep -v amdgpu.ids $OUT/ab_lga.txt
+fi
+if has modeltests; then
+  echo "== model tests (reference models on the drop-in, GPU vs CPU-oracle twin)"
+  SECONDS=0
+  timeout 600 python -m pytest tests/test_gpu_model.py -m gpu -q -s > $OUT/pytest_model.txt 2>&1; echo "model pytest rc=$? (${SECONDS}s)"; grep -E "gpu vs|fused vs|MODE_B|passed|failed" $OUT/pytest_model.txt
+fi
+if has model; then
+  echo "== cfg3 inference (GANet_deep 1248x384)"
+  SECONDS=0
+  timeout 600 python -m harness.infer --kernel_share > $OUT/infer_stock.json 2> $OUT/infer_stock.err; echo "infer rc=$? (${SECONDS}s)"; cat $OUT/infer_stock.json; tail -3 $OUT/infer_stock.err
+  timeout 400 python -m harness.infer --fused --kernel_share > $OUT/infer_fused.json 2> $OUT/infer_fused.err; echo "infer fused rc=$?"; cat $OUT/infer_fused.json; tail -3 $OUT/infer_fused.err
+  echo "== cfg4 per-GPU training step (GANet_deep 240x624, 1 sample)"
+  SECONDS=0
+  timeout 600 python -m harness.train --steps 5 --warmup 2 --kernel_share > $OUT/train_stock.json 2> $OUT/train_stock.err; echo "train rc=$? (${SECONDS}s)"; cat $OUT/train_stock.json; tail -3 $OUT/train_stock.err
+  timeout 400 python -m harness.train --steps 5 --warmup 2 --fused --kernel_share > $OUT/train_fused.json 2> $OUT/train_fused.err; echo "train fused rc=$?"; cat $OUT/train_fused.json; tail -3 $OUT/train_fused.err
+fi
+if has nofind; then
+  echo "== MIOpen immediate mode (PyTorch default) for comparison"
+  timeout 400 python -m harness.infer --no_miopen_find > $OUT/infer_nofind.json 2> $OUT/infer_nofind.err; echo "rc=$?"; cat $OUT/infer_nofind.json
+  timeout 400 python -m harness.train --no_miopen_find --steps 3 --warmup 1 > $OUT/train_nofind.json 2> $OUT/train_nofind.err; echo "rc=$?"; cat $OUT/train_nofind.json
+fi
+# keep the MIOpen products for the next call if they are small enough to come back
+du -sh /tmp/miopen 2>/dev/null
+if [ "$(du -sm /tmp/miopen | cut -f1)" -lt 40 ]; then mkdir -p $OUT/miopen_cache && cp -r /tmp/miopen/. $OUT/miopen_cache/; fi
+# trim the raw traces (only the stats travel well)
+find $OUT -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null
+echo "== done"

@@ -1,0 +1,52 @@
+"""Static check of the hand-counted-vmcnt kernels: inside the main loop of each LDS-DMA kernel the compiler must not have added
+vector-memory operations of its own (register spills = scratch_load / scratch_store count in vmcnt and would silently break the
+explicit s_waitcnt vmcnt(n) bookkeeping).  python scripts/isa_loop_check.py [asm file]   (no GPU needed; exits 1 on a finding)"""
+import os, re, subprocess, sys, tempfile
+from collections import Counter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+KERNELS = ["lga_apply_dma", "lga_filter_grad_dma", "lga_apply_pp", "lga_filter_grad_pp"]
+
+
+def asm_text(path=None):
+    if path:
+        return open(path).read()
+    from ganet_amd import build
+    with tempfile.NamedTemporaryFile(suffix=".s") as tf:
+        subprocess.run(["hipcc"] + build.HIPCC_FLAGS + ["-I", build.CSRC, "-S", "--cuda-device-only",
+                        os.path.join(build.CSRC, "ganet_capi.hip"), "-o", tf.name], check=True, stderr=subprocess.DEVNULL)
+        return open(tf.name).read()
+
+
+def main():
+    txt = asm_text(sys.argv[1] if len(sys.argv) > 1 else None)
+    lines = txt.split("\n")
+    bad = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN2ga\d+(" + "|".join(KERNELS) + r")I\S+):", l)
+        if not m:
+            continue
+        end = next(j for j in range(i, len(lines)) if "s_endpgm" in lines[j])
+        body = lines[i:end]
+        labels = {mm.group(1): k for k, bl in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", bl)] if mm}
+        loops = []
+        for k, bl in enumerate(body):
+            mm = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", bl)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < k:
+                loops.append((k - labels[mm.group(1)], labels[mm.group(1)], k))
+        if not loops:
+            continue
+        _, a, b = max(loops)
+        ops = Counter(bl.split()[0] for bl in body[a:b + 1] if bl.strip() and not bl.strip().startswith((";", ".")))
+        scr = sum(v for k, v in ops.items() if k.startswith("scratch_"))
+        valu = sum(v for k, v in ops.items() if k.startswith("v_"))
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.split("(")[0].replace("void ga::", "")
+        print(f"{name:44s} loop: {valu:4d} VALU ({ops.get('v_pk_fma_f32', 0)} pk_fma, {ops.get('v_pk_mul_f32', 0)} pk_mul)  "
+              f"{ops.get('ds_read_b64', 0):3d} ds_read_b64  {sum(v for k, v in ops.items() if 'load_lds' in k):3d} lds-dma  "
+              f"{ops.get('s_waitcnt', 0):3d} waits  scratch-in-loop {scr}" + ("   <-- UNSAFE" if scr else ""))
+        bad += scr > 0
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

