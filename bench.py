@@ -8,9 +8,10 @@ One STEP = one cost volume as GA-Net feeds the ops at crop 240x624, max_disp 192
 fp32, synthetic inputs resident in HBM before the timed region, torch.manual_seed(123).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by the driver as torch.distributed.run, one rank per GPU; ranks run independent
-cost volumes (the ops have no cross-sample term, so there is no data-path collective): weak
-scaling, value = N*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver as torch.distributed.run, one rank per GPU (without a launcher this file re-executes
+itself that way); ranks run independent cost volumes (the ops have no cross-sample term, so there is no data-path
+collective; the barrier / max-over-ranks timing protocol runs over gloo on the host): weak scaling,
+value = N*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline      HBM roofline of the dominant kernel family (largest share of the step), from
@@ -158,8 +159,8 @@ _FAMILY_KERNELS = {
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
                      ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false>"]],
-    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_dma<2>", "lga_apply_dma<2, true>"]],
-    "lga_apply (fwd pass)": [["lga_apply_dma<2, false>"]],
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp<2, 3, 0>", "lga_apply_pp<2, true>"]],
+    "lga_apply (fwd pass)": [["lga_apply_pp<2, false>"]],
 }
 
 
@@ -336,7 +337,11 @@ def main():
     if args.stub_step:
         return stub_main(args)
 
-    ctx = gdist.init(args.gpus)
+    # The op benchmark has NO data-path collective (ranks own independent cost volumes): the only cross-rank traffic is the
+    # timing protocol (two barriers and one max-reduction of a scalar).  That runs over gloo on the host, so no collective
+    # ever shares a stream with -- or is captured into -- the timed hipGraph; RCCL over xGMI is what the training harness
+    # (harness/train.py: DistributedDataParallel, backend "nccl") uses for its gradient all-reduce.
+    ctx = gdist.init(args.gpus, backend="gloo")
     device = torch.device("cuda", ctx.local_rank)
     torch.cuda.set_device(device)
     from ganet_amd import _native

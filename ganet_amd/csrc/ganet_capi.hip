@@ -64,7 +64,7 @@ struct Options {
   std::atomic<int> gd_v{4};
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
-  std::atomic<int> lga_wave{2};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
   std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
   std::atomic<int> lga_vmcnt_safe{0};   // 1: the LDS-DMA kernels never count result stores when they wait for a staged plane (waits earlier than necessary)
   std::atomic<int> lga_segs{0};   // depth segments per tile for those kernels (0 = automatic)
@@ -482,6 +482,7 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
     sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
     const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
     sg.split_a = 0;
+    sg.safe_wait = opts().lga_vmcnt_safe ? 1 : 0;
     sg.nseg = lga_segments((int)(tiles < (1 << 30) ? tiles : (1 << 30)), D, transposed);
     sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
     sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
@@ -499,7 +500,17 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
       }
     }
     if (opts().lga_wave == 3 && (i64)H * W < (1ll << 28)) {
-      // plane-pair kernel: segments start on even planes (32-bit byte offsets inside a plane pair)
+      // plane-pair kernel: segments start on even planes (32-bit byte offsets inside a plane pair).  Measured at 240x624x193
+      // (profiles/r2e_ab_lga_plane_pairs_v2.txt): ONE segment is best for both the forward (0.099 ms) and the data-backward --
+      // every work item pays the weight gather and a pipeline fill (0.038 ms of a 0.107 ms pass in the ablation,
+      // profiles/r2f_lga_pp_ablation.txt) -- unless there are too few tiles to fill the chip
+      if (opts().lga_segs <= 0 && opts().lga_split <= 1) {
+        const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
+        sg.split_a = 0;
+        sg.nseg = tiles * 2 > slots ? 1 : (int)((slots + tiles - 1) / tiles);
+        if (sg.nseg > D / 16) sg.nseg = D / 16 > 1 ? D / 16 : 1;
+        sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
+      }
       if (sg.split_a > 0) sg.split_a &= ~1;
       if (sg.split_a <= 0) {
         sg.split_a = 0;
@@ -508,14 +519,8 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
       }
       const i64 items_pp = tiles * sg.nseg;
       if constexpr (R <= 2) if (items_pp < (1ll << 31)) {
-        const bool relaxed = !opts().lga_vmcnt_safe;
-        if (transposed) {
-          if (relaxed) GA_LAUNCH((lga_apply_pp<R, true, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-          else GA_LAUNCH((lga_apply_pp<R, true, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        } else {
-          if (relaxed) GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-          else GA_LAUNCH((lga_apply_pp<R, false, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        }
+        if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
+        else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
         if (getenv("GANET_TRACE_DISPATCH")) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d split=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg, sg.split_a);
         return check_launch("lga apply (plane pairs)");
       }
@@ -551,7 +556,7 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
       LgaSeg sg;
       sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
       sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0;
+      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
       const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
       if (items < (1ll << 31)) {
         if (opts().lga_fg_wps == 2) GA_LAUNCH((lga_filter_grad_pp<R, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
@@ -565,7 +570,7 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
       LgaSeg sg;
       sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
       sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0;
+      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
       const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
       if (items < (1ll << 31)) {
         GA_LAUNCH((lga_filter_grad_dma<R>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);

@@ -30,6 +30,7 @@
 // DESIGN.md.
 #pragma once
 #include "ga_common.h"
+#include <type_traits>
 
 namespace ga {
 
@@ -364,6 +365,7 @@ template <int R> struct LgaWCfg {
 struct LgaSeg {
   int nseg, seg_len, tiles_x, tiles_y;
   int split_a;
+  int safe_wait;      // lga_apply_dma: never count y stores when waiting for a staged plane (GANET_LGA_VMCNT_SAFE)
 };
 
 // item -> (tile bx, by, batch b, depth range); each XCD (block id % 8) gets a contiguous band of tiles
@@ -738,8 +740,8 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
         // issues exactly one: some lane of a tile is always inside the image)
         int kk = k;
         GA_OPAQUE_S(kk);                                   // (keeps the compiler from splitting the plane loop by range)
-        if (kk >= P + 1 && kk < nvis) GA_VMCNT(2 * (P - 1));
-        else GA_VMCNT(P - 1);
+        if (!sg.safe_wait && kk >= P + 1 && kk < nvis) GA_VMCNT(2 * (P - 1));
+        else GA_VMCNT(P - 1);                              // (always sufficient: the stores only make it earlier than needed)
         GA_WAVE_SYNC();
       }
       {
@@ -834,6 +836,9 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
 #ifndef LGAP_NR
 #define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
 #endif
+#ifndef LGAP_ABLATE
+#define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs
+#endif
 template <int R> struct LgaPCfg {
   static constexpr int WS = 2 * R + 1;
   static constexpr int TW2 = LGA_TW + 2 * R;               // no alignment padding: a cell is 8 bytes wherever it is
@@ -886,29 +891,45 @@ template <int HALF> GA_DEV f2 mul2_bcast(f2 X, f2 W)
 #endif
 }
 
-// all ND copies of one plane pair: copy k moves lane l's dword from base + off[k] (bytes) to slot + 256 k + 4 l.  One M0
-// save / restore around the batch (M0 = LDS base of the copy; a write to M0 needs one wait state before the copy that
-// uses it).  Scalar base + 32-bit lane offset: the offsets are the same for every pair, only the base moves.
-#define GA_PP_COPY(n) "s_nop 0\n\tglobal_load_lds_dword %" #n ", %2\n\ts_add_u32 m0, m0, 0x100\n\t"
+// all ND copies of one plane pair: copy k moves lane l's dword from base + off[k] (bytes) to slot + 256 k + 4 l, scalar base +
+// 32-bit lane offset (the offsets are the same for every pair, only the base moves).  M0 holds the LDS base of the batch and
+// is saved / restored around it (a write to M0 needs one wait state before the copy that uses it).
+// LGAP_IMM_OFFSET = 1: the instruction's immediate offset is added to BOTH addresses of an LDS-DMA copy (global and LDS), so
+// ONE M0 value serves the whole batch: copy k carries offset:256 k and its lane offsets are stored 256 k lower (the caller
+// passes `base` LGAP_BIAS bytes low and offsets LGAP_BIAS bytes high so that they stay non-negative) -- ND + 4 instructions
+// per batch instead of 3 ND + 3.  LGAP_IMM_OFFSET = 0 advances M0 between the copies instead.
+#ifndef LGAP_IMM_OFFSET
+#define LGAP_IMM_OFFSET 1
+#endif
+constexpr unsigned LGAP_BIAS = LGAP_IMM_OFFSET ? 4096u : 0u;
+GA_DEV unsigned lga_pp_off(unsigned byte_off, int k) { return byte_off + LGAP_BIAS - (LGAP_IMM_OFFSET ? 256u * (unsigned)k : 0u); }
+#if LGAP_IMM_OFFSET
+#define GA_PP_COPY(n, k) "global_load_lds_dword %" #n ", %2 offset:" #k "\n\t"
+#else
+#define GA_PP_COPY(n, k) "s_nop 0\n\tglobal_load_lds_dword %" #n ", %2\n\ts_add_u32 m0, m0, 0x100\n\t"
+#endif
 template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&o)[ND], float *slot, int lane)
 {
 #if defined(GA_HIPSIM)
-  for (int k = 0; k < ND; k++) slot[k * 64 + lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k]);
+  for (int k = 0; k < ND; k++)
+    slot[k * 64 + lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + (LGAP_IMM_OFFSET ? 256 * k : 0));
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
   static_assert(ND == 5 || ND == 7 || ND == 10, "copy batch written out for R = 1, 2, 3");
   if constexpr (ND == 5)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
-                 "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]) : "memory", "scc");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+                 GA_PP_COPY(7, 1024) "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]) : "memory", "scc");
   else if constexpr (ND == 7)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
-                 GA_PP_COPY(8) GA_PP_COPY(9) "s_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+                 GA_PP_COPY(7, 1024) GA_PP_COPY(8, 1280) GA_PP_COPY(9, 1536) "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]) : "memory", "scc");
   else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" GA_PP_COPY(3) GA_PP_COPY(4) GA_PP_COPY(5) GA_PP_COPY(6) GA_PP_COPY(7)
-                 GA_PP_COPY(8) GA_PP_COPY(9) GA_PP_COPY(10) GA_PP_COPY(11) GA_PP_COPY(12) "s_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+                 GA_PP_COPY(7, 1024) GA_PP_COPY(8, 1280) GA_PP_COPY(9, 1536) GA_PP_COPY(10, 1792) GA_PP_COPY(11, 2048) GA_PP_COPY(12, 2304)
+                 "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]),
                    "v"(o[8]), "v"(o[9]) : "memory", "scc");
 #endif
@@ -957,7 +978,7 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
   }
 }
 
-template <int R, bool TRANSPOSED, bool RELAXED_WAIT>
+template <int R, bool TRANSPOSED>
 __global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
              LgaGeom geo, LgaSeg sg)
@@ -997,9 +1018,10 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
     int i2 = ty0 + r - R, j2 = tx0 + c - R;
     i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
     j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
-    goff[k] = 4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2));      // (launcher: 2 HW floats < 2^30)
+    goff[k] = lga_pp_off(4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2)), k);   // (launcher: 2 HW floats < 2^30)
   }
-  const float *gbase = xb + (i64)(2 * m_lo) * geo.HW;      // uniform: even plane of the next pair to request
+  // uniform: even plane of the next pair to request, LGAP_BIAS bytes low (see lga_dma4p_all)
+  const float *gbase = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + (i64)(2 * m_lo) * geo.HW) - LGAP_BIAS);
   // pairs are requested in order q = 0, 1, 2, ... (relative to m_lo); past the last one the last is requested again so that
   // the operation count per step stays fixed.  half: the pair's odd plane does not exist (2 m + 1 == D).
   int dma_slot = 0;
@@ -1051,12 +1073,23 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
   f2 o_prev = mk2(0.f, 0.f);                     // O_{m-1} so far: (y[2m-1], y[2m]) contributions of pair m-1
   float e_hi_prev = 0.f;                         // E_{m-1}.hi
   float xc_prev = 0.f;                           // centre sample of plane 2m-1
-  int slot_c = 0;
+  // ring positions as running float offsets (no multiplications in the march)
+  int soff_c = 0;                                // slot of the pair being computed
+  int soff_d = (P % NR) * PC::SLOT;              // slot the next copy batch goes to (== dma_slot * SLOT)
   // the row ring has LA + 1 entries and a pair has WS rows: unroll U pairs so that the ring closes (U * WS % (LA + 1) == 0)
   constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
   constexpr int NSTEP = U * WS;
   static_assert(NSTEP % (LA + 1) == 0, "row ring must close");
-  for (int q0 = 0; q0 < npair; q0 += U) {
+
+  // One group = U pair-steps.  What limits these kernels is the NUMBER of instructions a wave has to issue per plane, of
+  // any kind (profiles/r1p_pmc_summary.txt: scalar bookkeeping took as much wave time as the FMAs; cutting 20 % of the VALU
+  // alone changed nothing, profiles/r2d_ab_lga_plane_pairs_v1.txt), so the march has two bodies: STEADY -- every step is a
+  // full pair with both outputs inside the segment, plain centre coefficient and a full pair to request: no predicates, no
+  // index arithmetic beyond three ring offsets and the output pointer -- and the general
+  // one for the first and last groups of a segment.
+  float *yp = yb + pix;                                        // (re-seated when the steady groups begin)
+  auto group = [&](auto steady_tag, int q0) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
     f2 eA, eB, pA, pB, cA, cB;                   // E_m, O_{m-1} increment, O_m: two chains each
     f2 xc2 = mk2(0.f, 0.f);
 #pragma unroll
@@ -1064,34 +1097,56 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
       const int u = st / WS, a = st % WS;
       const int q = q0 + u;
       const int m = m_lo + q;
-      if (a == 0) dma(q + P);                    // overwrites the slot of pair q - 1, whose rows have all been consumed
-      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
-      const lds_cptr cur = lbase + slot_c * PC::SLOT, nxt = lbase + slot_n * PC::SLOT;
+      if (a == 0) {                              // overwrites the slot of pair q - 1, whose rows have all been consumed
+        if (STEADY) {
+#if !(LGAP_ABLATE & 1)
+          lga_dma4p_all<ND>(gbase, goff, ring + soff_d, lane);
+#endif
+          gbase += 2 * geo.HW;
+          dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
+        } else {
+          dma(q + P);
+        }
+        soff_d = soff_d + PC::SLOT == NR * PC::SLOT ? 0 : soff_d + PC::SLOT;
+      }
+      const int soff_n = soff_c + PC::SLOT == NR * PC::SLOT ? 0 : soff_c + PC::SLOT;
+      const lds_cptr cur = lbase + soff_c, nxt = lbase + soff_n;
       if (a == WS - LA) {
-        // pair q + 1 must have landed.  After its copies came those of P - 1 further pairs and, once the march is under way,
-        // the two y stores of each of the P - 1 steps in between (every step from the second on issues exactly two: some
-        // lane of a tile is always inside the image).  RELAXED_WAIT = false ignores the stores (waits earlier than needed).
-        int qq = q;
-        GA_OPAQUE_S(qq);
-        if (RELAXED_WAIT && qq >= P + 1 && qq + 1 < npair && m_lo + qq - P >= (d_lo >> 1) + 1) GA_VMCNT((ND + 2) * (P - 1));
-        else GA_VMCNT(ND * (P - 1));
+        // pair q + 1 must have landed.  After its copies came those of P - 1 further pairs (and y stores, which only make
+        // this wait earlier than necessary: counting them -- vmcnt((ND + 2)(P - 1)) -- was measured and bought nothing,
+        // profiles/r2e_ab_lga_plane_pairs_v2.txt, so the count that needs no assumption about the stores is the only one)
+#if !(LGAP_ABLATE & 3)
+        GA_VMCNT(ND * (P - 1));
+#endif
         GA_WAVE_SYNC();
       }
       {
         const int t = a + LA;
         const lds_cptr src = t < WS ? cur + 2 * t * PC::TW2 : nxt + 2 * (t - WS) * PC::TW2;
 #pragma unroll
-        for (int bb = 0; bb < WS; bb++) vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
+        for (int bb = 0; bb < WS; bb++) {
+#if LGAP_ABLATE & 4
+          if (STEADY) GA_KEEP_F2(vrow[(st + LA) % (LA + 1)][bb]);
+          else
+#endif
+          vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
+        }
       }
       GA_SCHED_FENCE();
+      // taps of the row from the LAST one read to the first: the wait for the last covers the whole row (LDS returns in
+      // order), so a row costs one s_waitcnt instead of one per tap
 #pragma unroll
-      for (int bb = 0; bb < WS; bb++) {
+      for (int b2 = 0; b2 < WS; b2++) {
+        const int bb = WS - 1 - b2;
         const f2 X = vrow[st % (LA + 1)][bb];
         const int tm = (0 * WS + a) * WS + bb, t0 = (1 * WS + a) * WS + bb, tp = (2 * WS + a) * WS + bb;   // slabs -1, 0, +1
-        const int n = a * WS + bb;                        // taps alternate between two chains per accumulator
+        const int n = a * WS + b2;                        // taps alternate between two chains per accumulator
 #define GA_PP_ACC(acc, t)                                                                                    \
         acc = n < 2 ? ((t & 1) ? mul2_bcast<1>(X, wq[t >> 1]) : mul2_bcast<0>(X, wq[t >> 1]))               \
                     : ((t & 1) ? fma2_bcast<1>(X, wq[t >> 1], acc) : fma2_bcast<0>(X, wq[t >> 1], acc))
+#if LGAP_ABLATE & 8
+        if (STEADY && n >= 2) { GA_KEEP_F2(eA); } else
+#endif
         if (n & 1) { GA_PP_ACC(eB, t0); GA_PP_ACC(pB, tp); GA_PP_ACC(cB, tm); }
         else { GA_PP_ACC(eA, t0); GA_PP_ACC(pA, tp); GA_PP_ACC(cA, tm); }
 #undef GA_PP_ACC
@@ -1100,32 +1155,63 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
       }
       if (a == WS - 1) {
         GA_KEEP_F2(eA); GA_KEEP_F2(eB); GA_KEEP_F2(pA); GA_KEEP_F2(pB); GA_KEEP_F2(cA); GA_KEEP_F2(cB);
-        const bool live = q < npair;                       // uniform
         const f2 e = add2(eA, eB);
         const f2 o = add2(o_prev, add2(pA, pB));           // O_{m-1} complete
-        const int d1 = 2 * m - 1, d2 = 2 * m;
-        if (live && d1 >= d_lo && d1 < d_hi) {
-          float cc = cmid;
-          if (d1 == D - 1) cc += sin_p;                    // (d1 is odd: never plane 0)
-          const float r = fmaf(xc_prev, cc, e_hi_prev + o.x);
-          if (inb) yb[(i64)d1 * geo.HW + pix] = r;
-        }
-        if (live && d2 >= d_lo && d2 < d_hi) {
-          float cc = cmid;
-          if (d2 == 0) cc += sin_m;
-          if (d2 == D - 1) cc += sin_p;
-          const float r = fmaf(xc2.x, cc, e.x + o.y);
-          if (inb) yb[(i64)d2 * geo.HW + pix] = r;
-        }
-        if (live) {
+        if (STEADY) {
+          const float r1 = fmaf(xc_prev, cmid, e_hi_prev + o.x);      // y[2m-1]
+          const float r2 = fmaf(xc2.x, cmid, e.x + o.y);              // y[2m]
+#if LGAP_ABLATE & 2
+          if (inb && r1 == 123.456f) yp[0] = r1 + r2;
+          yp += 2 * geo.HW;
+#else
+          if (inb) yp[0] = r1;
+          yp += geo.HW;
+          if (inb) yp[0] = r2;
+          yp += geo.HW;
+#endif
           o_prev = add2(cA, cB);
           e_hi_prev = e.y;
           xc_prev = xc2.y;
+        } else {
+          const bool live = q < npair;                       // uniform
+          const int d1 = 2 * m - 1, d2 = 2 * m;
+          if (live && d1 >= d_lo && d1 < d_hi) {
+            float cc = cmid;
+            if (d1 == D - 1) cc += sin_p;                    // (d1 is odd: never plane 0)
+            const float r = fmaf(xc_prev, cc, e_hi_prev + o.x);
+            if (inb) yb[(i64)d1 * geo.HW + pix] = r;
+          }
+          if (live && d2 >= d_lo && d2 < d_hi) {
+            float cc = cmid;
+            if (d2 == 0) cc += sin_m;
+            if (d2 == D - 1) cc += sin_p;
+            const float r = fmaf(xc2.x, cc, e.x + o.y);
+            if (inb) yb[(i64)d2 * geo.HW + pix] = r;
+          }
+          if (live) {
+            o_prev = add2(cA, cB);
+            e_hi_prev = e.y;
+            xc_prev = xc2.y;
+          }
         }
-        slot_c = slot_n;
+        soff_c = soff_n;
       }
     }
+  };
+  // steady steps q in [ql, qh): q + P a full pair inside the segment's request range; both outputs inside
+  // [max(d_lo, 1), min(d_hi, D - 1))
+  const int ql = ((d_lo + 2) >> 1) - m_lo;
+  int qh = npair - P;
+  if ((D >> 1) - m_lo - P < qh) qh = (D >> 1) - m_lo - P;
+  {
+    const int L = d_hi < D - 1 ? d_hi : D - 1;
+    if (((L - 2 * m_lo + 1) >> 1) < qh) qh = (L - 2 * m_lo + 1) >> 1;
   }
+  int q0 = 0;
+  for (; q0 < npair && q0 < ql; q0 += U) group(std::false_type{}, q0);
+  if (q0 + U <= qh) yp = yb + (i64)(2 * (m_lo + q0) - 1) * geo.HW + pix;
+  for (; q0 + U <= qh; q0 += U) group(std::true_type{}, q0);
+  for (; q0 < npair; q0 += U) group(std::false_type{}, q0);
   {
     // even D at the end of the volume: plane D - 1 = 2 m_hi + 1 has no later pair to be completed by
     const int d1 = 2 * m_hi + 1;
@@ -1215,11 +1301,12 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
     int i2 = ty0 + r - R, j2 = tx0 + c - R;
     i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
     j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
-    goff[k] = 4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2));
+    goff[k] = lga_pp_off(4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2)), k);
     goff_lds[k * 64 + lane] = goff[k];
   }
   const unsigned gyoff = 4u * (unsigned)pix;
-  const float *xsrc = xb;                              // uniform: even plane of the next x pair to request
+  // uniform: even plane of the next x pair to request, LGAP_BIAS bytes low (see lga_dma4p_all)
+  const float *xsrc = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb) - LGAP_BIAS);
   const float *gysrc = gyb;                            // uniform: next gy plane to request
   int dma_slot = 0, g_slot = 0;
   auto dma_x = [&](int q, bool reload) {               // x pair q (past the end: the last pair again, fixed operation count)
@@ -1276,28 +1363,47 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
 #pragma unroll
     for (int bb = 0; bb < WS; bb++) vrow[s0][bb] = lds_read_b64(lbase + 2 * (s0 * PC::TW2 + bb));
   }
-  int slot_c = 0;
+  int soff_c = 0;                                // x ring: float offset of the slot of the pair being visited
+  int soff_d = (P % NR) * PC::SLOT;              //         ... of the slot the next copy batch goes to
   int gs = 0;                                    // gy ring slot of plane 2q
   constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
   constexpr int NSTEP = U * WS;
-  for (int q0 = 0; q0 < npair; q0 += U) {
+  // two bodies as in lga_apply_pp: STEADY = a step whose requests (x pair q + P, gy planes 2(q+P)+1, +2) and multipliers
+  // (gy planes 2q-1 .. 2q+2) all exist and which touches neither end of the volume -- no predicates, no clamping
+  auto group = [&](auto steady_tag, int q0) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
     f2 Ga = mk2(0.f, 0.f), Gb = mk2(0.f, 0.f), Gc = mk2(0.f, 0.f);
     f2 xc2 = mk2(0.f, 0.f);
 #pragma unroll
     for (int st = 0; st < NSTEP; st++) {
       const int u = st / WS, a = st % WS;
       const int q = q0 + u;
-      const bool live = q < npair;                         // uniform
+      const bool live = STEADY || q < npair;               // uniform
       if (a == 0) {
         // the slots these overwrite held x pair q - 1 and gy planes 2q - 3, 2q - 2: all consumed (the lanes of a wave run in
         // lockstep; the wave barrier is a compiler fence here and a real one in the CPU emulator)
         GA_WAVE_SYNC();
-        dma_g(2 * (q + P) + 1);
-        dma_g(2 * (q + P) + 2);
-        dma_x(q + P, true);
+        if (STEADY) {
+          lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
+          gysrc += geo.HW;
+          g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
+          lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
+          gysrc += geo.HW;
+          g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
+#pragma unroll
+          for (int k = 0; k < ND; k++) goff[k] = goff_lds[k * 64 + lane];
+          lga_dma4p_all<ND>(xsrc, goff, ring + soff_d, lane);
+          xsrc += 2 * geo.HW;
+          dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
+        } else {
+          dma_g(2 * (q + P) + 1);
+          dma_g(2 * (q + P) + 2);
+          dma_x(q + P, true);
+        }
+        soff_d = soff_d + PC::SLOT == NR * PC::SLOT ? 0 : soff_d + PC::SLOT;
       }
-      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
-      const lds_cptr cur = lbase + slot_c * PC::SLOT, nxt = lbase + slot_n * PC::SLOT;
+      const int soff_n = soff_c + PC::SLOT == NR * PC::SLOT ? 0 : soff_c + PC::SLOT;
+      const lds_cptr cur = lbase + soff_c, nxt = lbase + soff_n;
       if ((a + LA) % WS == 0) {
         // the rows read from here on belong to x pair q + 1 (LA > 0) or q (LA = 0): it -- and with it gy up to two planes
         // past it -- must have landed.  After its last copy came VPS operations for each later pair up to q + P.
@@ -1308,16 +1414,22 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
         // gy[2q-1 .. 2q+2] of the own pixel (0 outside [0, D)); all landed: they precede x pair q in issue order
         const int s_m1 = gs == 0 ? NGS - 1 : gs - 1, s_p1 = gs + 1 == NGS ? 0 : gs + 1, s_p2 = s_p1 + 1 == NGS ? 0 : s_p1 + 1;
         const float gm1v = gbase[s_m1 * 64];
-        const float gm1 = (q > 0 && live) ? gm1v : 0.f;
         const float g0v = gbase[gs * 64];
         const float g1v = gbase[s_p1 * 64], g2v = gbase[s_p2 * 64];
-        const float g1 = 2 * q + 1 < D ? g1v : 0.f;
-        const float g2 = 2 * q + 2 < D ? g2v : 0.f;
-        const float g0 = live ? g0v : 0.f;                 // a step past the last pair runs on zero multipliers (no branch
+        if (STEADY) {
+          Ga = mk2(g1v, g0v);
+          Gb = mk2(g2v, g1v);
+          Gc = mk2(gm1v, g0v);
+        } else {
+          const float gm1 = (q > 0 && live) ? gm1v : 0.f;
+          const float g1 = 2 * q + 1 < D ? g1v : 0.f;
+          const float g2 = 2 * q + 2 < D ? g2v : 0.f;
+          const float g0 = live ? g0v : 0.f;               // a step past the last pair runs on zero multipliers (no branch
                                                            // around the FMAs: the 100 accumulators would meet at a merge)
-        Ga = mk2(g1, g0);
-        Gb = mk2(g2, g1);
-        Gc = mk2(gm1, g0);
+          Ga = mk2(g1, g0);
+          Gb = mk2(g2, g1);
+          Gc = mk2(gm1, g0);
+        }
       }
       {
         const int t = a + LA;
@@ -1326,15 +1438,18 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
         for (int bb = 0; bb < WS; bb++) vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
       }
       GA_SCHED_FENCE();
+      // last tap read first: its wait covers the row (LDS returns in order)
 #pragma unroll
-      for (int bb = 0; bb < WS; bb++) {
+      for (int b2 = 0; b2 < WS; b2++) {
+        const int bb = WS - 1 - b2;
         const f2 X = vrow[st % (LA + 1)][bb];
         Pq[a][bb] = fma2(mk2(X.x, X.x), Ga, Pq[a][bb]);     // (a splat of a freshly loaded value: the compiler's own op_sel)
         Qq[a][bb] = fma2(X, Gc, Qq[a][bb]);
         if (a == R && bb == R) xc2 = X;
       }
 #pragma unroll
-      for (int bb = 0; bb < WS; bb++) {
+      for (int b2 = 0; b2 < WS; b2++) {
+        const int bb = WS - 1 - b2;
         const f2 X = vrow[st % (LA + 1)][bb];
         Pq[a][bb] = fma2(mk2(X.y, X.y), Gb, Pq[a][bb]);
       }
@@ -1344,15 +1459,23 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
           // Ga = (g[2q+1], g[2q]) (zeros past the end), centre samples xc2 = (x[2q][c], x[2q+1][c])
           const float e0 = Ga.y * xc2.x, e1 = Ga.x * xc2.y;
           gc += e0 + e1;
-          if (q == 0) e_lo = e0;
-          if (2 * q == D - 1) e_hi = e0;
-          if (2 * q + 1 == D - 1) e_hi = e1;
+          if (!STEADY) {
+            if (q == 0) e_lo = e0;
+            if (2 * q == D - 1) e_hi = e0;
+            if (2 * q + 1 == D - 1) e_hi = e1;
+          }
         }
-        slot_c = slot_n;
+        soff_c = soff_n;
         gs = gs + 2 >= NGS ? gs + 2 - NGS : gs + 2;
       }
     }
-  }
+  };
+  // steady steps: 1 <= q and 2 (q + P) + 2 <= D - 1
+  const int qh = (D - 1 - 2 * P) >> 1;
+  int q0 = 0;
+  for (; q0 < npair && q0 < 1; q0 += U) group(std::false_type{}, q0);
+  for (; q0 + U <= qh; q0 += U) group(std::true_type{}, q0);
+  for (; q0 < npair; q0 += U) group(std::false_type{}, q0);
   GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
 
   // Everything the write-out needs about the pixel is recomputed here from an opaque copy of the lane id: kept live

@@ -211,7 +211,10 @@ int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: segment kernels)
  *   GANET_SGA_MERGE4 = 0|1  four-pixels-per-lane merge + arg-max (default 1)
  *   GANET_SGA_POINT_BLOCK = 64|128|256  threads per block of the per-pixel gradient kernel (default 256)
- *   GANET_LGA_WAVE = 0|1|2  LGA kernels: 256-thread tiles | wave-autonomous, register staging | wave-autonomous, LDS-DMA (default 2)
+ *   GANET_LGA_WAVE = 0|1|2|3  LGA kernels: 256-thread tiles | wave-autonomous, register staging | wave-autonomous, LDS-DMA,
+ *                         FMAs packed along window columns | wave-autonomous, LDS-DMA, FMAs packed along plane pairs (default 3)
+ *   GANET_LGA_FG_WPS = 2|3  plane-pair filter gradient: register budget for 2 or 3 waves per SIMD (default 3)
+ *   GANET_LGA_VMCNT_SAFE = 0|1  lga_apply_dma (GANET_LGA_WAVE=2): never count result stores in the wait for a staged plane
  *   GANET_LGA_SEGS = n      depth segments per tile for the wave-autonomous LGA kernels (0 = automatic) */
 int ganet_set_option(const char *name, int value);
 

@@ -8,8 +8,13 @@ import torch
 import torch.nn.functional as F
 from ganet_amd import _native
 
+args = [a for a in sys.argv[1:] if not a.startswith("--lib=")]
+libname = [a[6:] for a in sys.argv[1:] if a.startswith("--lib=")]
+if libname:                                     # a variant build (scripts/build_variants.py): ganet_amd/<name>
+    _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname[0]))
 lib = _native.lib()
-shape = tuple(int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (1, 193, 240, 624)
+print("library:", lib.path)
+shape = tuple(int(v) for v in args[0:4]) if len(args) >= 4 else (1, 193, 240, 624)
 B, D, H, W = shape
 torch.manual_seed(0)
 x = torch.randn(shape, device="cuda")
@@ -31,8 +36,7 @@ def timed(fn, iters=20):
 
 variants = [dict(GANET_LGA_WAVE=2), dict(GANET_LGA_WAVE=3), dict(GANET_LGA_WAVE=3, GANET_LGA_FG_WPS=2),
             dict(GANET_LGA_WAVE=3, GANET_LGA_VMCNT_SAFE=1),
-            dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=1), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=2), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=3),
-            dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=4), dict(GANET_LGA_WAVE=2, GANET_LGA_SEGS=2), dict(GANET_LGA_WAVE=0)]
+            dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=1), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=2), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=3)]
 base = None
 for rep in range(2):
     for v in variants:

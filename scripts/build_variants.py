@@ -15,7 +15,7 @@ def one(spec):
         obj = os.path.join(build.CSRC, f"{src}.{tag}.o")
         cmd = ["hipcc"] + build.HIPCC_FLAGS + extra + [f for f in flags.split(",") if f] + ["-I", build.CSRC, "-c", os.path.join(build.CSRC, src), "-o", obj]
         subprocess.run(cmd, check=True); objs.append(obj)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC"] + objs + ["-o", out], check=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(out)] + objs + ["-o", out], check=True)
     for o in objs: os.remove(o)
     return out
 with ThreadPoolExecutor(4) as ex:

@@ -6,7 +6,7 @@ TAG=${1:-r2}
 PARTS=${2:-"tests smoke bench prof model"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-mkdir -p $OUT
+mkdir -p $OUT $OUT/pmc
 cd $ROOT
 export TMPDIR=/tmp
 # MIOpen: no gfx950 find-db / kernel-db ships with the image; keep what this box compiles and bring back what an
@@ -41,9 +41,27 @@ if has prof; then
   ( cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace --output-format csv -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" )
   find $OUT/prof -name '*kernel_stats*' | head -1 | xargs -r head -16
 fi
+if has pmc; then
+  echo "== memory-side PMC passes (traffic per kernel at the L2 <-> fabric boundary)"
+  ( cd /tmp; i=0
+    for SET in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+               "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_DRAM_sum" \
+               "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc/p$i -o pmc --output-format csv -- python $ROOT/scripts/prof_stage.py all 2 > $OUT/pmc/p$i.log 2>&1
+      echo "pmc set $i rc=$?"
+    done )
+  python scripts/pmc_summary.py $OUT/pmc > $OUT/pmc/summary.txt 2>&1
+  python scripts/pmc_traffic.py $OUT/pmc/summary.txt $OUT/traffic_pmc.json > /dev/null 2>&1; echo "traffic rc=$?"
+  find $OUT/pmc -name '*.csv' -size +2M -delete 2>/dev/null
+fi
 if has ablga; then
   echo "== LGA kernel families A/B"
   timeout 400 python scripts/ab_lga.py > $OUT/ab_lga.txt 2>&1; echo "ab_lga rc=$?"; grep -v amdgpu.ids $OUT/ab_lga.txt
+  for v in ganet_amd/libganet_hip_*.so; do
+    [ -f $v ] || continue
+    n=$(basename $v); timeout 300 python scripts/ab_lga.py --lib=$n > $OUT/ab_lga_$n.txt 2>&1; echo "ab_lga $n rc=$?"; grep -v amdgpu.ids $OUT/ab_lga_$n.txt
+  done
 fi
 if has modeltests; then
   echo "== model tests (reference models on the drop-in, GPU vs CPU-oracle twin)"

@@ -36,15 +36,21 @@ def main():
                 loops.append((k - labels[mm.group(1)], labels[mm.group(1)], k))
         if not loops:
             continue
-        _, a, b = max(loops)
-        ops = Counter(bl.split()[0] for bl in body[a:b + 1] if bl.strip() and not bl.strip().startswith((";", ".")))
-        scr = sum(v for k, v in ops.items() if k.startswith("scratch_"))
-        valu = sum(v for k, v in ops.items() if k.startswith("v_"))
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.split("(")[0].replace("void ga::", "")
-        print(f"{name:44s} loop: {valu:4d} VALU ({ops.get('v_pk_fma_f32', 0)} pk_fma, {ops.get('v_pk_mul_f32', 0)} pk_mul)  "
-              f"{ops.get('ds_read_b64', 0):3d} ds_read_b64  {sum(v for k, v in ops.items() if 'load_lds' in k):3d} lds-dma  "
-              f"{ops.get('s_waitcnt', 0):3d} waits  scratch-in-loop {scr}" + ("   <-- UNSAFE" if scr else ""))
-        bad += scr > 0
+        seen = set()
+        for _, a, b in sorted(loops, reverse=True):
+            if any(a >= a0 and b <= b0 for a0, b0 in seen):
+                continue                                   # nested inside a loop already reported
+            ops = Counter(bl.split()[0] for bl in body[a:b + 1] if bl.strip() and not bl.strip().startswith((";", ".")))
+            if ops.get("v_pk_fma_f32", 0) < 20:
+                continue
+            seen.add((a, b))
+            scr = sum(v for k, v in ops.items() if k.startswith("scratch_"))
+            valu = sum(v for k, v in ops.items() if k.startswith("v_"))
+            print(f"{name:40s} loop@{a:5d}: {sum(ops.values()):4d} instr, {valu:4d} VALU ({ops.get('v_pk_fma_f32', 0)} pk_fma, {ops.get('v_pk_mul_f32', 0)} pk_mul)  "
+                  f"{ops.get('ds_read_b64', 0):3d} ds_read_b64  {sum(v for k, v in ops.items() if 'load_lds' in k):3d} lds-dma  "
+                  f"{ops.get('s_waitcnt', 0):3d} waits  scratch-in-loop {scr}" + ("   <-- UNSAFE" if scr else ""))
+            bad += scr > 0
     sys.exit(1 if bad else 0)
 
 

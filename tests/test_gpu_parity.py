@@ -265,8 +265,8 @@ def test_cost_volume_and_regression(api, dev, port_oracle):
 @pytest.mark.parametrize("shape", [(1, 193, 384, 1248), (2, 193, 528, 960), (1, 193, 241, 624)])
 def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
     """The LGA shapes of BASELINE configs 3 and 5 (KITTI 1248x384; SceneFlow 960x528, 2 samples per GPU) and an odd
-    height: the wave-autonomous LDS-DMA kernels (default) and the 256-thread tile kernels (GANET_LGA_WAVE=0) are
-    different kernel families and must agree to fp32 rounding, forward, data gradient and filter gradient; the
+    height: the plane-pair kernels (default, GANET_LGA_WAVE=3), the column-packed LDS-DMA kernels (2) and the 256-thread
+    tile kernels (0) are different kernel families and must agree to fp32 rounding, forward, data gradient and filter gradient; the
     bilinear identity <y, gy> == <x, gX> == <f, gF> holds for both -- no oracle in the loop."""
     torch = dev.torch
     B, D, H, W = shape
@@ -276,7 +276,7 @@ def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
     gy = torch.randn(shape, device="cuda", generator=g)
     res = {}
     try:
-        for mode in (2, 0):
+        for mode in (3, 2, 0):
             api.set_option("GANET_LGA_WAVE", mode)
             y, gx, gf = torch.empty_like(xl), torch.empty_like(xl), torch.empty_like(f)
             api.call("ganet_lga_forward", xl.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, dev.stream)
@@ -285,10 +285,11 @@ def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
             torch.cuda.synchronize()
             res[mode] = (y, gx, gf)
     finally:
-        api.set_option("GANET_LGA_WAVE", 2)
-    for a, b in zip(res[2], res[0]):
-        assert (a - b).abs().max().item() <= 2e-5, (a - b).abs().max().item()
-    y, gx, gf = res[2]
+        api.set_option("GANET_LGA_WAVE", 3)
+    for other in (2, 0):
+        for a, b in zip(res[3], res[other]):
+            assert (a - b).abs().max().item() <= 6e-5, (other, (a - b).abs().max().item())
+    y, gx, gf = res[3]
     a = (y.double() * gy.double()).sum().item()
     b = (xl.double() * gx.double()).sum().item()
     c = (f.double() * gf.double()).sum().item()
@@ -407,3 +408,48 @@ def test_cost_volume_and_regression_cfg2_size(api, dev, port_oracle):
     gp = dev.empty(p.shape)
     api.call("ganet_disparity_regression_backward", dev.to(go).data_ptr(), gp.data_ptr(), 1, 193, 240, 624, dev.stream)
     assert np.array_equal(dev.host(gp), go[:, None] * np.arange(193, dtype=np.float32)[None, :, None, None])
+
+
+@pytest.mark.parametrize("shape,segs", [((1, 193, 240, 624), 0), ((1, 33, 7, 36), 2), ((2, 9, 3, 64), 3), ((1, 5, 66, 132), 0),
+                                        ((1, 64, 13, 100), 2), ((1, 2, 2, 4), 0)])
+def test_lga_dma_wait_modes_and_kernel_families(api, dev, port_oracle, shape, segs):
+    """the column-packed LDS-DMA kernel (GANET_LGA_WAVE=2) relaxes its wait for a staged plane by the y stores it
+    expects in between; GANET_LGA_VMCNT_SAFE=1 never counts them.  Both modes must give bit-identical results on edge
+    tiles, split depth ranges (d_lo > 0) and small D, and the plane-pair kernels (3, whose copies go through immediate
+    offsets on ONE M0 value) must agree with them to fp32 rounding -- a miscounted wait or a misplaced copy reads a stale or
+    foreign ring slot and shows up as an O(1) difference."""
+    torch = dev.torch
+    B, D, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + segs)
+    x = torch.randn(shape, device="cuda", generator=g)
+    f = torch.nn.functional.normalize(torch.randn((B, 75, H, W), device="cuda", generator=g), p=1, dim=1)
+    gy = torch.randn(shape, device="cuda", generator=g)
+    res = {}
+    try:
+        api.set_option("GANET_LGA_SEGS", segs)
+        for tag, wave, safe in (("dma", 2, 0), ("dma_safe", 2, 1), ("pp", 3, 0)):
+            api.set_option("GANET_LGA_WAVE", wave)
+            api.set_option("GANET_LGA_VMCNT_SAFE", safe)
+            outs = []
+            for rep in range(3):           # repeated: a race would not be deterministic
+                y, gx, gf = torch.full_like(x, float("nan")), torch.full_like(x, float("nan")), torch.full_like(f, float("nan"))
+                api.call("ganet_lga_forward", x.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, dev.stream)
+                api.call("ganet_lga_backward", x.data_ptr(), f.data_ptr(), gy.data_ptr(), gx.data_ptr(), gf.data_ptr(),
+                         B, D, H, W, 2, 0, dev.stream)
+                torch.cuda.synchronize()
+                outs.append((y, gx, gf))
+            for o in outs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(o, outs[0])), (tag, "not reproducible")
+            res[tag] = outs[0]
+    finally:
+        api.set_option("GANET_LGA_WAVE", 3)
+        api.set_option("GANET_LGA_VMCNT_SAFE", 0)
+        api.set_option("GANET_LGA_SEGS", 0)
+    assert all(torch.equal(a, b) for a, b in zip(res["dma"], res["dma_safe"]))
+    for a, b in zip(res["pp"], res["dma"]):
+        assert (a - b).abs().max().item() <= 6e-5
+    if x.numel() <= 4_000_000:
+        y, ins = port_oracle.lga_chain_forward(x.cpu().numpy(), f.cpu().numpy(), 2, 1)
+        ogx, ogf = port_oracle.lga_chain_backward(ins, f.cpu().numpy(), gy.cpu().numpy(), 2)
+        for got, want in zip(res["pp"], (y, ogx, ogf)):
+            assert np.abs(got.cpu().numpy() - want).max() <= pc.TOL

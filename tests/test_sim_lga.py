@@ -150,3 +150,26 @@ def test_plane_pair_filter_gradient_variants(sim, port_oracle, shape, r, wps):
     finally:
         sim.set_option("GANET_LGA_WAVE", 1)
         sim.set_option("GANET_LGA_FG_WPS", 3)
+
+
+@pytest.mark.parametrize("segs,split", [(1, 1), (2, 1), (0, 24), (0, 40)])
+@pytest.mark.parametrize("shape", [(1, 65, 3, 34), (1, 64, 2, 36), (2, 47, 2, 40)])
+def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs, split):
+    """lga_apply_pp on depth ranges long enough to reach its predicate-free steady body (several groups of pair steps), with
+    the body changes at every possible phase: one segment, two equal ones, and unequal splits; odd and even D."""
+    rng = np.random.default_rng(sum(shape) + segs + split)
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((shape[0], 75) + shape[2:]), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y = port_oracle.lga_forward(x, f, 2)
+    gx, gf = port_oracle.lga_backward(x, f, gy, 2)
+    sim.set_option("GANET_LGA_WAVE", 3)
+    sim.set_option("GANET_LGA_SEGS", segs)
+    sim.set_option("GANET_LGA_SPLIT", split)
+    try:
+        err = pc.check_lga_chain(sim, DEV, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_SEGS", 0)
+        sim.set_option("GANET_LGA_SPLIT", 1)
