@@ -1018,6 +1018,43 @@ GA_EXPORT int ganet_norm_disparity_regression_backward(const float *x, const flo
   return check_launch("normalised disparity regression backward");
 }
 
+namespace {
+int check_up(const char *who, const void *a, const void *b, int S, int Di, int Hi, int Wi, int Do, int Ho, int Wo)
+{
+  if (!a || !b) return fail(GANET_E_INVALID, "%s: null pointer", who);
+  if (S <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0)
+    return fail(GANET_E_INVALID, "%s: non-positive size", who);
+  return GANET_OK;
+}
+UpAxis up_axis(int in, int out)
+{
+  UpAxis a;
+  a.in = in; a.out = out;
+  a.scale = (float)in / (float)out;      // ATen: area_pixel_compute_scale<float>(in, out, align_corners = false, nullopt)
+  return a;
+}
+}  // namespace
+
+GA_EXPORT int ganet_trilinear_upsample_forward(const float *x, float *y, int S, int Di, int Hi, int Wi, int Do, int Ho,
+                                               int Wo, void *stream)
+{
+  GA_TRY(check_up("ganet_trilinear_upsample_forward", x, y, S, Di, Hi, Wi, Do, Ho, Wo));
+  const i64 total = (i64)S * Do * Ho * Wo;
+  GA_LAUNCH(trilinear_up_fwd, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, x, y, (i64)S, up_axis(Di, Do),
+            up_axis(Hi, Ho), up_axis(Wi, Wo));
+  return check_launch("trilinear upsample forward");
+}
+
+GA_EXPORT int ganet_trilinear_upsample_backward(const float *grad_y, float *grad_x, int S, int Di, int Hi, int Wi, int Do,
+                                                int Ho, int Wo, void *stream)
+{
+  GA_TRY(check_up("ganet_trilinear_upsample_backward", grad_y, grad_x, S, Di, Hi, Wi, Do, Ho, Wo));
+  const i64 total = (i64)S * Di * Hi * Wi;
+  GA_LAUNCH(trilinear_up_bwd, dim3(ew_grid(total)), dim3(256), (hipStream_t)stream, grad_y, grad_x, (i64)S, up_axis(Di, Do),
+            up_axis(Hi, Ho), up_axis(Wi, Wo));
+  return check_launch("trilinear upsample backward");
+}
+
 GA_EXPORT int ganet_softmin_forward(const float *x, float *y, int N, int Dn, int H, int W, void *stream)
 {
   if (!x || !y) return fail(GANET_E_INVALID, "ganet_softmin_forward: null pointer");

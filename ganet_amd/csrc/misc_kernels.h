@@ -488,4 +488,126 @@ softmin_regression_bwd(const float *__restrict__ x, const float *__restrict__ ou
   }
 }
 
+// ---- trilinear up-sampling of a volume (Disp / DispAgg.forward, models/GANet_deep.py:212, 240) -----------------------------
+// y = F.interpolate(x, size=[Do, Ho, Wo], mode='trilinear', align_corners=False) on [S, Di, Hi, Wi] -> [S, Do, Ho, Wo]
+// (S = N * C slices).  Per axis, PyTorch's rule (area_pixel_compute_source_index): src = max(scale * (o + 0.5) - 0.5, 0)
+// with scale = in / out as float, i0 = floor(src), i1 = min(i0 + 1, in - 1), weights (1 - l, l), l = src - i0.
+// The forward is a plain 8-point gather.  The BACKWARD is a gather too: one lane per INPUT voxel sums the (up to ~6^3 at a
+// 3x zoom) output gradients whose interpolation footprint contains it, weights recomputed on the fly -- where ATen's
+// upsample_trilinear3d_backward issues eight atomicAdds per OUTPUT element (22.5 ms of a 114 ms GANet-deep training step
+// for its three calls on [1,1,193,240,624], profiles/r2_model_train_stock.json).
+struct UpAxis {
+  int in, out;
+  float scale;      // (float)in / out
+};
+GA_DEV void up_src(const UpAxis &ax, int o, int &i0, int &i1, float &l1)
+{
+  float src = ax.scale * ((float)o + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 < ax.in - 1 ? i0 : ax.in - 1;
+  i1 = i0 + (i0 < ax.in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);     // (guard_index_and_lambda)
+}
+// weight with which output o reads input i (0 if it does not)
+GA_DEV float up_weight(const UpAxis &ax, int o, int i)
+{
+  int i0, i1; float l1;
+  up_src(ax, o, i0, i1, l1);
+  return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+// outputs that can read input i: [lo, hi] (a superset by at most one on each side; up_weight() decides)
+GA_DEV void up_range(const UpAxis &ax, int i, int &lo, int &hi)
+{
+  const float inv = (float)ax.out / (float)ax.in;
+  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > ax.out - 1 ? ax.out - 1 : hi;
+}
+
+static __global__ void __launch_bounds__(256)
+trilinear_up_fwd(const float *__restrict__ x, float *__restrict__ y, i64 S, UpAxis ad, UpAxis ah, UpAxis aw)
+{
+  // one lane per output element, w fastest (coalesced stores; the 8 reads hit a volume 27x smaller: cache resident)
+  const i64 total = S * ad.out * ah.out * aw.out;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int ow = (int)(e % aw.out);
+    i64 r = e / aw.out;
+    const int oh = (int)(r % ah.out); r /= ah.out;
+    const int od = (int)(r % ad.out);
+    const i64 sl = r / ad.out;
+    int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
+    up_src(ad, od, d0, d1, ld);
+    up_src(ah, oh, h0, h1, lh);
+    up_src(aw, ow, w0, w1, lw);
+    const float *xs = x + sl * ad.in * ah.in * aw.in;
+    const i64 p00 = ((i64)d0 * ah.in + h0) * aw.in, p01 = ((i64)d0 * ah.in + h1) * aw.in;
+    const i64 p10 = ((i64)d1 * ah.in + h0) * aw.in, p11 = ((i64)d1 * ah.in + h1) * aw.in;
+    // ATen's order: (1-ld) * ((1-lh) * ((1-lw) a + lw b) + lh * (...)) + ld * (...)
+    const float a00 = (1.f - lw) * xs[p00 + w0] + lw * xs[p00 + w1];
+    const float a01 = (1.f - lw) * xs[p01 + w0] + lw * xs[p01 + w1];
+    const float a10 = (1.f - lw) * xs[p10 + w0] + lw * xs[p10 + w1];
+    const float a11 = (1.f - lw) * xs[p11 + w0] + lw * xs[p11 + w1];
+    y[e] = (1.f - ld) * ((1.f - lh) * a00 + lh * a01) + ld * ((1.f - lh) * a10 + lh * a11);
+  }
+}
+
+constexpr int UP_MAXFP = 12;     // outputs per axis that can read one input (zoom <= ~5; larger zooms take the slow loop)
+static __global__ void __launch_bounds__(256)
+trilinear_up_bwd(const float *__restrict__ gy, float *__restrict__ gx, i64 S, UpAxis ad, UpAxis ah, UpAxis aw)
+{
+  // one lane per INPUT voxel, w fastest: neighbouring lanes read neighbouring (overlapping) runs of gy
+  const i64 total = S * ad.in * ah.in * aw.in;
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int iw = (int)(e % aw.in);
+    i64 r = e / aw.in;
+    const int ih = (int)(r % ah.in); r /= ah.in;
+    const int id = (int)(r % ad.in);
+    const i64 sl = r / ad.in;
+    int dlo, dhi, hlo, hhi, wlo, whi;
+    up_range(ad, id, dlo, dhi);
+    up_range(ah, ih, hlo, hhi);
+    up_range(aw, iw, wlo, whi);
+    const float *gs = gy + sl * ad.out * ah.out * aw.out;
+    float acc = 0.f;
+    if (whi - wlo < UP_MAXFP) {
+      float ww[UP_MAXFP];
+#pragma unroll
+      for (int k = 0; k < UP_MAXFP; k++) ww[k] = wlo + k <= whi ? up_weight(aw, wlo + k, iw) : 0.f;
+      for (int od = dlo; od <= dhi; od++) {
+        const float wd = up_weight(ad, od, id);
+        if (wd == 0.f) continue;
+        for (int oh = hlo; oh <= hhi; oh++) {
+          const float wdh = wd * up_weight(ah, oh, ih);
+          if (wdh == 0.f) continue;
+          const float *row = gs + ((i64)od * ah.out + oh) * aw.out;
+          float t = 0.f;
+#pragma unroll
+          for (int k = 0; k < UP_MAXFP; k++) {
+            const int ow = wlo + k <= whi ? wlo + k : whi;       // clamped address, zero weight past the range
+            t = fmaf(ww[k], row[ow], t);
+          }
+          acc = fmaf(wdh, t, acc);
+        }
+      }
+    } else {
+      for (int od = dlo; od <= dhi; od++) {
+        const float wd = up_weight(ad, od, id);
+        for (int oh = hlo; oh <= hhi; oh++) {
+          const float wdh = wd * up_weight(ah, oh, ih);
+          const float *row = gs + ((i64)od * ah.out + oh) * aw.out;
+          float t = 0.f;
+          for (int ow = wlo; ow <= whi; ow++) t = fmaf(up_weight(aw, ow, iw), row[ow], t);
+          acc = fmaf(wdh, t, acc);
+        }
+      }
+    }
+    gx[e] = acc;
+  }
+}
+
 }  // namespace ga

@@ -14,7 +14,7 @@ from .. import _native
 from .GANet import _check, _p, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
-           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction"]
+           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction"]
 
 
 def _lib():
@@ -178,4 +178,33 @@ class SoftminDisparityRegressionFunction(Function):
             gx = torch.empty_like(x)
             _lib().call("ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ssum), _p(g), _p(gx),
                         N, D, H, W, _stream())
+        return gx, None
+
+
+class TrilinearUpsampleFunction(Function):
+    """F.interpolate(x, size, mode='trilinear', align_corners=False) on [N,C,D,H,W] (the cost-volume up-sampling of
+    Disp.forward / DispAgg.forward, models/GANet_deep.py:212, 240) with a GATHER backward: one lane per input voxel sums the
+    output gradients that read it, instead of ATen's eight atomicAdds per output element."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        _check(x)
+        if x.dim() != 5 or len(size) != 3:
+            raise ValueError("TrilinearUpsample expects [N,C,D,H,W] and a 3-element output size")
+        N, C, Di, Hi, Wi = x.shape
+        Do, Ho, Wo = (int(v) for v in size)
+        ctx.dims = (N, C, Di, Hi, Wi, Do, Ho, Wo)
+        with torch.cuda.device_of(x):
+            y = torch.empty((N, C, Do, Ho, Wo), dtype=x.dtype, device=x.device)
+            _lib().call("ganet_trilinear_upsample_forward", _p(x), _p(y), N * C, Di, Hi, Wi, Do, Ho, Wo, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = gy.contiguous()
+        _check(g)
+        N, C, Di, Hi, Wi, Do, Ho, Wo = ctx.dims
+        with torch.cuda.device_of(g):
+            gx = torch.empty((N, C, Di, Hi, Wi), dtype=g.dtype, device=g.device)
+            _lib().call("ganet_trilinear_upsample_backward", _p(g), _p(gx), N * C, Di, Hi, Wi, Do, Ho, Wo, _stream())
         return gx, None

@@ -4,11 +4,11 @@ import torch
 from torch.nn.modules.module import Module
 
 from ..functions.fused import (NormDisparityRegressionFunction, SoftminDisparityRegressionFunction, SoftminFunction,
-                               normalize_filters, normalize_guidance, sga_forward_infer)
+                               TrilinearUpsampleFunction, normalize_filters, normalize_guidance, sga_forward_infer)
 from ..functions.GANet import Lga2Function, SgaFunction
 
 __all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "SoftminDisparityRegression",
-           "DispAggTail"]
+           "DispAggTail", "TrilinearUpsample"]
 
 
 class GuidedSGA(Module):
@@ -92,3 +92,11 @@ class DispAggTail(Module):
         x = SoftminFunction.apply(x.contiguous())
         x = self.lga(x, lg2)
         return self.disparity(x)
+
+
+class TrilinearUpsample(Module):
+    """F.interpolate(x, size, mode='trilinear', align_corners=False) for [N,C,D,H,W] volumes: the up-sampling in front of
+    the Softmin / LGA tails (models/GANet_deep.py:212, 240), with a gather backward (see TrilinearUpsampleFunction)."""
+
+    def forward(self, x, size):
+        return TrilinearUpsampleFunction.apply(x.contiguous(), tuple(int(v) for v in size))

@@ -5,18 +5,22 @@ rebinding `forward` on the SGABlock / DispAgg / Disp instances.
   SGABlock.forward  models/GANet_deep.py:262-277   split + view + 4x normalize + SGA (+ bn_relu) -> GuidedSGABnRelu
   DispAgg.forward   models/GANet_deep.py:239-247   after the upsampling: lga, Softmin, lga, normalize, regression -> DispAggTail
   Disp.forward      models/GANet_deep.py:213-219   after the upsampling: Softmin + regression -> SoftminDisparityRegression
+  both tails        models/GANet_deep.py:212, 240  F.interpolate(trilinear) -> TrilinearUpsample (gather backward instead of
+                                                   ATen's atomics: 22.5 ms of a 114 ms training step, profiles/r2_model_train_stock.json)
 """
 import types
 
 import torch
-import torch.nn.functional as F
 
-from ganet_amd.modules.fused import DispAggTail, GuidedSGA, GuidedSGABnRelu, SoftminDisparityRegression
+from ganet_amd.modules.fused import (DispAggTail, GuidedSGA, GuidedSGABnRelu, SoftminDisparityRegression,
+                                     TrilinearUpsample)
+
+_UP = TrilinearUpsample()
 
 
 def _upsampled(self, x):
-    x = F.interpolate(self.conv32x1(x), [self.maxdisp + 1, x.size()[3] * 3, x.size()[4] * 3], mode="trilinear",
-                      align_corners=False)
+    # (the reference: F.interpolate(..., mode='trilinear', align_corners=False), models/GANet_deep.py:212, 240)
+    x = _UP(self.conv32x1(x), [self.maxdisp + 1, x.size()[3] * 3, x.size()[4] * 3])
     return torch.squeeze(x, 1)
 
 

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 4
+#define GANET_ABI_VERSION 5
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -194,6 +194,15 @@ int ganet_softmin_regression_forward(const float *x, float *out, float *mx, floa
 int ganet_softmin_regression_backward(const float *x, const float *out, const float *mx, const float *ssum,
                                       const float *grad_out, float *grad_x,
                                       int N, int Dn, int H, int W, void *stream);
+
+/* y [S,Do,Ho,Wo] = F.interpolate(x [S,Di,Hi,Wi], size=[Do,Ho,Wo], mode='trilinear', align_corners=False) per slice
+ * (S = N * C), and its adjoint.  Replaces: the up-sampling of the cost volume in Disp.forward / DispAgg.forward
+ * (models/GANet_deep.py:212, 240), i.e. ATen's upsample_trilinear3d and -- the point -- upsample_trilinear3d_backward,
+ * which scatters with eight atomicAdds per output element; the backward here is a gather per input voxel. */
+int ganet_trilinear_upsample_forward(const float *x, float *y, int S, int Di, int Hi, int Wi,
+                                     int Do, int Ho, int Wo, void *stream);
+int ganet_trilinear_upsample_backward(const float *grad_y, float *grad_x, int S, int Di, int Hi, int Wi,
+                                      int Do, int Ho, int Wo, void *stream);
 
 /* ---------------------------------------------------------------- diagnostics ---- */
 

@@ -26,7 +26,7 @@ fi
 if has tests; then
   echo "== pytest -m gpu (ops)"
   SECONDS=0
-  timeout 1500 python -m pytest tests -m gpu -x -q -s --deselect tests/test_gpu_model.py > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$? (${SECONDS}s)"; tail -25 $OUT/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q -s --deselect tests/test_gpu_model.py > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$? (${SECONDS}s)"; tail -25 $OUT/pytest_gpu.txt
 fi
 if has smoke; then
   echo "== smoke"

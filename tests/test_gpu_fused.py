@@ -160,3 +160,38 @@ def test_softmin_disparity_regression_full_size(torch_mod):
     ref.backward(go)
     np.testing.assert_allclose(_np(out), _np(ref), rtol=1e-5, atol=1e-4)
     assert (x.grad - x2.grad).abs().max().item() <= 1e-4 * max(1.0, x2.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("ishape,osize", [((1, 1, 65, 80, 208), (193, 240, 624)), ((2, 3, 9, 16, 32), (25, 48, 96)),
+                                          ((1, 2, 7, 5, 6), (10, 13, 17))])
+def test_trilinear_upsample_vs_aten(torch_mod, ishape, osize):
+    """TrilinearUpsample (gather backward) == F.interpolate(mode='trilinear', align_corners=False) and its autograd
+    adjoint, at the model's Disp / DispAgg shape ([1,1,65,80,208] -> [193,240,624], models/GANet_deep.py:212, 240) and two
+    small ones; prints both backward times at the full size."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.modules.fused import TrilinearUpsample
+    torch.manual_seed(sum(ishape))
+    x = torch.randn(ishape, device="cuda", requires_grad=True)
+    gy = torch.randn(ishape[:2] + osize, device="cuda")
+    y = TrilinearUpsample()(x, osize)
+    y.backward(gy)
+    x2 = x.detach().clone().requires_grad_()
+    y2 = F.interpolate(x2, size=list(osize), mode="trilinear", align_corners=False)
+    y2.backward(gy)
+    torch.cuda.synchronize()
+    assert float((y - y2).abs().max()) <= 1e-5
+    scale = max(1.0, float(x2.grad.abs().max()))
+    assert float((x.grad - x2.grad).abs().max()) <= 1e-5 * scale, float((x.grad - x2.grad).abs().max())
+    if ishape[2] == 65:
+        def timed(fn, n=5):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); e1.synchronize()
+            return e0.elapsed_time(e1) / n
+        t_ours = timed(lambda: torch.autograd.grad(TrilinearUpsample()(x, osize), x, gy))
+        t_aten = timed(lambda: torch.autograd.grad(F.interpolate(x2, size=list(osize), mode="trilinear", align_corners=False), x2, gy))
+        print(f"trilinear upsample [1,1,65,80,208] -> [193,240,624] fwd+bwd: ours {t_ours:.3f} ms, ATen {t_aten:.3f} ms")

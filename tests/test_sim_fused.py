@@ -150,3 +150,26 @@ def test_softmin_disparity_regression(sim, N, maxdisp, H, W):
     gx = np.full_like(x, np.nan)
     sim.call("ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ss), _p(go), _p(gx), N, D, H, W, None)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("isz,osz", [((3, 4, 5), (7, 12, 15)), ((5, 6, 7), (13, 18, 21)), ((4, 3, 6), (4, 3, 6)),
+                                     ((2, 5, 4), (9, 7, 22)), ((6, 8, 9), (3, 5, 4)), ((1, 1, 1), (4, 3, 2))])
+def test_trilinear_upsample_matches_torch(sim, isz, osz):
+    """ganet_trilinear_upsample_forward / _backward against F.interpolate(mode='trilinear', align_corners=False) and its
+    autograd adjoint on the CPU: the 3x zoom of the models (65 -> 193 is 3x - 2: a non-integer ratio on the depth axis),
+    identity, a fractional zoom, down-sampling and a single voxel."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(sum(isz) + sum(osz))
+    S = 3
+    x = rng.standard_normal((1, S) + isz).astype(np.float32)
+    gy = rng.standard_normal((1, S) + osz).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_()
+    yt = F.interpolate(xt, size=list(osz), mode="trilinear", align_corners=False)
+    yt.backward(torch.from_numpy(gy))
+    y = np.full((1, S) + osz, np.nan, np.float32)
+    gx = np.full_like(x, np.nan)
+    sim.call("ganet_trilinear_upsample_forward", x.ctypes.data, y.ctypes.data, S, *isz, *osz, None)
+    sim.call("ganet_trilinear_upsample_backward", gy.ctypes.data, gx.ctypes.data, S, *isz, *osz, None)
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
