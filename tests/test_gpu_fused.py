@@ -71,12 +71,13 @@ def test_normalize_functions_match_torch(torch_mod):
     np.testing.assert_allclose(_np(g2.grad), g2c.grad.numpy(), rtol=1e-4, atol=1e-6)
 
 
-def test_dispagg_tail_matches_reference_statements(torch_mod, port_oracle):
-    """DispAggTail == models/GANet_deep.py:243-247 on a small volume (maxdisp 11), forward and all three gradients."""
+@pytest.mark.parametrize("maxdisp,H,W", [(11, 14, 36), (192, 24, 624)])
+def test_dispagg_tail_matches_reference_statements(torch_mod, port_oracle, maxdisp, H, W):
+    """DispAggTail == models/GANet_deep.py:243-247, forward and all three gradients: a small volume (maxdisp 11) and a
+    full-width strip at the models' maxdisp 192 ([1,193,24,624])."""
     torch = torch_mod
     from ganet_amd.modules.fused import DispAggTail
     torch.manual_seed(3)
-    maxdisp, H, W = 11, 14, 36
     x = torch.randn(1, maxdisp + 1, H, W, device="cuda", requires_grad=True)
     lg1 = torch.randn(1, 75, H, W, device="cuda", requires_grad=True)
     lg2 = torch.randn(1, 75, H, W, device="cuda", requires_grad=True)
@@ -87,7 +88,8 @@ def test_dispagg_tail_matches_reference_statements(torch_mod, port_oracle):
     xc, l1c, l2c = (t.detach().cpu().requires_grad_() for t in (x, lg1, lg2))
     want = fr.dispagg_tail(xc, l1c, l2c, maxdisp, port_oracle)
     want.backward(go.cpu())
-    np.testing.assert_allclose(_np(out), want.detach().numpy(), rtol=1e-5, atol=1e-4)
+    # disparities are sums of d * p_d with d up to maxdisp: the absolute bar scales with the range (1e-4 at maxdisp <= 10)
+    np.testing.assert_allclose(_np(out), want.detach().numpy(), rtol=2e-5, atol=1e-4 * max(1.0, maxdisp / 10.0))
     # five chained ops (two of them divisions by small L1 norms) amplify fp32 rounding: the gradients reach
     # |g| ~ 10^1..10^2 here, so the bar is 1e-4 RELATIVE to the largest gradient entry (>= 1e-4 absolute)
     for got, ref in ((x.grad, xc.grad), (lg1.grad, l1c.grad), (lg2.grad, l2c.grad)):
