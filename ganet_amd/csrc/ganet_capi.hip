@@ -545,6 +545,30 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   return check_launch("lga apply");
 }
 
+// one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
+template <int R>
+int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D, int H, int W,
+                           hipStream_t st)
+{
+  if constexpr (R <= 2) {
+    if ((i64)H * W < (1ll << 28)) {
+      LgaGeom geo;
+      geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+      LgaSeg sg;
+      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+      sg.nseg = 1; sg.seg_len = (D + 1) & ~1; sg.split_a = 0; sg.safe_wait = 0;
+      const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+      if (items < (1ll << 31)) {
+        GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
+        return check_launch("lga apply + regression epilogue (plane pairs)");
+      }
+    }
+  }
+  return fail(GANET_E_UNSUPPORTED, "ganet_lga_forward_regress: no fused kernel for this shape / radius: run ganet_lga_forward "
+                                   "and ganet_norm_disparity_regression_forward instead");
+}
+
 template <int R>
 int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc,
                   hipStream_t st)
@@ -864,6 +888,18 @@ GA_EXPORT int ganet_lga_forward(const float *x, const float *f, float *y, int B,
   if (radius == 1) return launch_lga_fwd<1>(x, f, y, B, D, H, W, false, st);
   if (radius == 2) return launch_lga_fwd<2>(x, f, y, B, D, H, W, false, st);
   return launch_lga_fwd<3>(x, f, y, B, D, H, W, false, st);
+}
+
+GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,
+                                        int H, int W, int radius, void *stream)
+{
+  if (!x || !f || !snorm || !sdy) return fail(GANET_E_INVALID, "ganet_lga_forward_regress: null pointer");
+  if (x == y) return fail(GANET_E_INVALID, "ganet_lga_forward_regress: y must not alias x");
+  GA_TRY(check_lga("ganet_lga_forward_regress", B, D, H, W, radius));
+  hipStream_t st = (hipStream_t)stream;
+  if (radius == 1) return launch_lga_fwd_regress<1>(x, f, y, snorm, sdy, B, D, H, W, st);
+  if (radius == 2) return launch_lga_fwd_regress<2>(x, f, y, snorm, sdy, B, D, H, W, st);
+  return launch_lga_fwd_regress<3>(x, f, y, snorm, sdy, B, D, H, W, st);
 }
 
 GA_EXPORT int ganet_lga_backward(const float *x, const float *f, const float *gy, float *gx,

@@ -978,10 +978,13 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
   }
 }
 
-template <int R, bool TRANSPOSED>
+// EPI: the pass also reduces its own output over the disparity axis per pixel -- snorm = sum_d |y|, sdy = sum_d d * y, what
+// F.normalize(p=1, dim=1) + DisparityRegression at the end of DispAgg.forward (models/GANet_deep.py:246-247) need -- and y
+// itself is stored only if the pointer is given (inference does not need it).  One depth segment per tile in that mode.
+template <int R, bool TRANSPOSED, bool EPI = false>
 __global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
 lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
-             LgaGeom geo, LgaSeg sg)
+             LgaGeom geo, LgaSeg sg, float *__restrict__ snorm_out = nullptr, float *__restrict__ sdy_out = nullptr)
 {
   typedef LgaPCfg<R> PC;
   constexpr int WS = PC::WS, K = WS * WS, NR = LGAP_NR, P = NR - 1, ND = PC::NDMA;
@@ -1058,7 +1061,9 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
     lga_gather_pairs<R, TRANSPOSED, true>(fb, geo, ic, jc, wq, cmid, sin_m, sin_p);
 
   // window rows stream through a register ring with LA rows of LDS look-ahead (rows of the NEXT pair for the last LA rows)
-  constexpr int LA = LGAW_LA;
+  // (the epilogue variant carries two more running sums and the plane index as a float: one row less of look-ahead keeps
+  // it spill-free -- a spill inside the march would break the hand-counted vmcnt, scripts/isa_loop_check.py)
+  constexpr int LA = EPI ? 1 : LGAW_LA;
   static_assert(WS > LA, "look-ahead must stay within the next pair");
   const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + 2 * (ty * PC::TW2 + tx);
   f2 vrow[LA + 1][WS];
@@ -1088,6 +1093,8 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
   // index arithmetic beyond three ring offsets and the output pointer -- and the general
   // one for the first and last groups of a segment.
   float *yp = yb + pix;                                        // (re-seated when the steady groups begin)
+  const bool store_y = !EPI || y != nullptr;                   // uniform
+  float e_abs = 0.f, e_dy = 0.f;                               // EPI: sum_d |y[d]|, sum_d d * y[d] of the own pixel
   auto group = [&](auto steady_tag, int q0) {
     constexpr bool STEADY = decltype(steady_tag)::value;
     f2 eA, eB, pA, pB, cA, cB;                   // E_m, O_{m-1} increment, O_m: two chains each
@@ -1164,11 +1171,15 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
           if (inb && r1 == 123.456f) yp[0] = r1 + r2;
           yp += 2 * geo.HW;
 #else
-          if (inb) yp[0] = r1;
+          if (inb && store_y) yp[0] = r1;
           yp += geo.HW;
-          if (inb) yp[0] = r2;
+          if (inb && store_y) yp[0] = r2;
           yp += geo.HW;
 #endif
+          if (EPI) {
+            e_abs += fabsf(r1) + fabsf(r2);
+            e_dy = fmaf((float)(2 * m - 1), r1, fmaf((float)(2 * m), r2, e_dy));
+          }
           o_prev = add2(cA, cB);
           e_hi_prev = e.y;
           xc_prev = xc2.y;
@@ -1179,14 +1190,16 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
             float cc = cmid;
             if (d1 == D - 1) cc += sin_p;                    // (d1 is odd: never plane 0)
             const float r = fmaf(xc_prev, cc, e_hi_prev + o.x);
-            if (inb) yb[(i64)d1 * geo.HW + pix] = r;
+            if (inb && store_y) yb[(i64)d1 * geo.HW + pix] = r;
+            if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d1, r, e_dy); }
           }
           if (live && d2 >= d_lo && d2 < d_hi) {
             float cc = cmid;
             if (d2 == 0) cc += sin_m;
             if (d2 == D - 1) cc += sin_p;
             const float r = fmaf(xc2.x, cc, e.x + o.y);
-            if (inb) yb[(i64)d2 * geo.HW + pix] = r;
+            if (inb && store_y) yb[(i64)d2 * geo.HW + pix] = r;
+            if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d2, r, e_dy); }
           }
           if (live) {
             o_prev = add2(cA, cB);
@@ -1219,8 +1232,14 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
       float cc = cmid;
       if (d1 == D - 1) cc += sin_p;
       const float r = fmaf(xc_prev, cc, e_hi_prev + o_prev.x);
-      if (inb) yb[(i64)d1 * geo.HW + pix] = r;
+      if (inb && store_y) yb[(i64)d1 * geo.HW + pix] = r;
+      if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d1, r, e_dy); }
     }
+  }
+  if (EPI && inb) {
+    const i64 op = (i64)b * geo.HW + pix;
+    snorm_out[op] = e_abs;
+    sdy_out[op] = e_dy;
   }
   GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
 }

@@ -14,7 +14,7 @@ from .. import _native
 from .GANet import _check, _p, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
-           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction"]
+           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction", "LgaRegressFunction"]
 
 
 def _lib():
@@ -208,3 +208,55 @@ class TrilinearUpsampleFunction(Function):
             gx = torch.empty((N, C, Di, Hi, Wi), dtype=g.dtype, device=g.device)
             _lib().call("ganet_trilinear_upsample_backward", _p(g), _p(gx), N * C, Di, Hi, Wi, Do, Ho, Wo, _stream())
         return gx, None
+
+
+class LgaRegressFunction(Function):
+    """One LGA pass followed by F.normalize(p=1, dim=1) + DisparityRegression -- the last three statements of
+    DispAgg.forward (models/GANet_deep.py:245-247 after the first pass of the second LGA2) -- with the two reductions over
+    the disparity axis done in the LGA kernel's epilogue (ganet_lga_forward_regress): out = sum_d d*y / max(sum_d |y|, 1e-12)
+    is a per-pixel finish, and without autograd the volume y is never written."""
+
+    @staticmethod
+    def forward(ctx, x, filters, radius, ndisp):
+        _check(x, filters)
+        if x.dim() != 4 or x.shape[1] != ndisp:
+            raise ValueError(f"expected [N,{ndisp},H,W], got {tuple(x.shape)}")
+        N, D, H, W = x.shape
+        if tuple(filters.shape) != (N, 3 * (2 * radius + 1) ** 2, H, W):
+            raise ValueError("LGA filters must be [N, 3(2r+1)^2, H, W]")
+        ctx.radius, ctx.dims = radius, (N, D, H, W)
+        keep = any(ctx.needs_input_grad[:2])
+        with torch.cuda.device_of(x):
+            y = torch.empty_like(x) if keep else None
+            snorm = torch.empty((N, H, W), dtype=x.dtype, device=x.device)
+            sdy = torch.empty_like(snorm)
+            try:
+                _lib().call("ganet_lga_forward_regress", _p(x), _p(filters), _p(y) if keep else None, _p(snorm), _p(sdy),
+                            N, D, H, W, radius, _stream())
+                snorm.clamp_(min=1e-12)
+                out = sdy / snorm
+            except _native.GanetError as e:                # no fused kernel for this shape: the two separate entries
+                if "no fused kernel" not in str(e):
+                    raise
+                y = torch.empty_like(x)
+                out = sdy
+                _lib().call("ganet_lga_forward", _p(x), _p(filters), _p(y), N, D, H, W, radius, _stream())
+                _lib().call("ganet_norm_disparity_regression_forward", _p(y), _p(out), _p(snorm), N, D, H, W, _stream())
+        if keep:
+            ctx.save_for_backward(x, filters, y, out, snorm)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, filters, y, out, snorm = ctx.saved_tensors
+        g = grad_out.contiguous()
+        _check(g)
+        N, D, H, W = ctx.dims
+        with torch.cuda.device_of(g):
+            gy = torch.empty_like(y)
+            _lib().call("ganet_norm_disparity_regression_backward", _p(y), _p(out), _p(snorm), _p(g), _p(gy),
+                        N, D, H, W, _stream())
+            gx = torch.empty_like(x)
+            gf = torch.empty_like(filters)
+            _lib().call("ganet_lga_backward", _p(x), _p(filters), _p(gy), _p(gx), _p(gf), N, D, H, W, ctx.radius, 0, _stream())
+        return gx, gf, None, None

@@ -3,9 +3,10 @@ reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
 import torch
 from torch.nn.modules.module import Module
 
-from ..functions.fused import (NormDisparityRegressionFunction, SoftminDisparityRegressionFunction, SoftminFunction,
-                               TrilinearUpsampleFunction, normalize_filters, normalize_guidance, sga_forward_infer)
-from ..functions.GANet import Lga2Function, SgaFunction
+from ..functions.fused import (LgaRegressFunction, NormDisparityRegressionFunction, SoftminDisparityRegressionFunction,
+                               SoftminFunction, TrilinearUpsampleFunction, normalize_filters, normalize_guidance,
+                               sga_forward_infer)
+from ..functions.GANet import Lga2Function, LgaFunction, SgaFunction
 
 __all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "SoftminDisparityRegression",
            "DispAggTail", "TrilinearUpsample"]
@@ -79,19 +80,23 @@ class SoftminDisparityRegression(Module):
 
 class DispAggTail(Module):
     """DispAgg.forward after the trilinear upsampling (models/GANet_deep.py:243-247):
-    lga(x, lg1) -> Softmin(dim=1) -> lga(x, lg2) -> F.normalize(p=1, dim=1) -> DisparityRegression."""
+    lga(x, lg1) -> Softmin(dim=1) -> lga(x, lg2) -> F.normalize(p=1, dim=1) -> DisparityRegression.
+    The last LGA pass carries the normalise + regression reductions in its epilogue (LgaRegressFunction): three LGA passes,
+    one Softmin, one fused pass and a per-pixel division -- under no_grad the final volume is never written."""
 
     def __init__(self, maxdisp=192, radius=2):
         super().__init__()
+        self.radius = radius
+        self.ndisp = maxdisp + 1
         self.lga = NormalizedLGA2(radius)
-        self.disparity = NormDisparityRegression(maxdisp)
 
     def forward(self, x, lg1, lg2):
         assert lg1.size() == lg2.size()
         x = self.lga(x, lg1)
         x = SoftminFunction.apply(x.contiguous())
-        x = self.lga(x, lg2)
-        return self.disparity(x)
+        f2 = normalize_filters(lg2)
+        x = LgaFunction.apply(x, f2, self.radius)                       # first pass of the second LGA2
+        return LgaRegressFunction.apply(x, f2, self.radius, self.ndisp)  # second pass + normalise + regression
 
 
 class TrilinearUpsample(Module):

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 5
+#define GANET_ABI_VERSION 6
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -129,6 +129,15 @@ int ganet_sga_backward_compat(const float *x, const float *g0, const float *g1, 
  *           accumulates into a zero-filled output; here the zero-fill is not needed. */
 int ganet_lga_forward(const float *x, const float *f, float *y,
                       int B, int D, int H, int W, int radius, void *stream);
+
+/* One LGA pass that also reduces its output over the disparity axis: snorm [B,H,W] = sum_d |y|, sdy [B,H,W] = sum_d d * y,
+ * so that F.normalize(y, p=1, dim=1) followed by DisparityRegression (the end of DispAgg.forward, models/GANet_deep.py:246-247)
+ * is sdy / max(snorm, 1e-12) -- a per-pixel finish instead of two more passes over the volume.  y may be NULL (inference:
+ * the volume itself is not needed); with y given it is written as by ganet_lga_forward (training keeps it for the backward,
+ * ganet_norm_disparity_regression_backward takes it together with out and snorm).  GANET_E_UNSUPPORTED where the fused kernel
+ * does not apply (radius 3, planes of 2^28 pixels or more): run the two separate entries instead. */
+int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy,
+                              int B, int D, int H, int W, int radius, void *stream);
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,

@@ -1,6 +1,8 @@
 """Kernel logic of the fused caller-side normalisations on the CPU emulator build, through the
 C ABI, against the reference's own torch statements executed on the CPU (oracle/fused_ref.py)."""
 import numpy as np
+
+import parity_cases as pc
 import pytest
 import torch
 
@@ -173,3 +175,25 @@ def test_trilinear_upsample_matches_torch(sim, isz, osz):
     sim.call("ganet_trilinear_upsample_backward", gy.ctypes.data, gx.ctypes.data, S, *isz, *osz, None)
     np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,r", [((1, 12, 5, 34), 2), ((2, 7, 3, 36), 2), ((1, 31, 2, 8), 2), ((1, 6, 4, 40), 1)])
+@pytest.mark.parametrize("with_y", [True, False])
+def test_lga_pass_with_regression_epilogue(sim, port_oracle, shape, r, with_y):
+    """ganet_lga_forward_regress: y (when asked for) equals the plain pass, snorm = sum_d |y| and sdy = sum_d d*y of the
+    oracle's output; y = NULL must not be touched."""
+    rng = np.random.default_rng(sum(shape) + r)
+    B, D, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 3 * (2 * r + 1) ** 2, H, W)), 1)
+    want = port_oracle.lga_forward(x, f, r)
+    y = np.full(shape, np.nan, np.float32)
+    snorm = np.full((B, H, W), np.nan, np.float32)
+    sdy = np.full((B, H, W), np.nan, np.float32)
+    sim.call("ganet_lga_forward_regress", x.ctypes.data, f.ctypes.data, y.ctypes.data if with_y else None, snorm.ctypes.data,
+             sdy.ctypes.data, B, D, H, W, r, None)
+    if with_y:
+        assert np.abs(y - want).max() < 2e-5
+    d = np.arange(D, dtype=np.float64)[None, :, None, None]
+    np.testing.assert_allclose(snorm, np.abs(want.astype(np.float64)).sum(1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sdy, (want.astype(np.float64) * d).sum(1), rtol=1e-5, atol=2e-4)
