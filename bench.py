@@ -283,7 +283,16 @@ def self_launch(n):
 def stub_main(args):
     """--stub-step: the launch / barrier / max-over-ranks / one-JSON-line protocol on CPU (gloo) with a placeholder
     step -- exercises the N > 1 plumbing where there is no GPU (tests/test_dist_gloo.py).  Not a measurement."""
-    ctx = gdist.init(args.gpus, backend="gloo")
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)                       # gloo announces its connections on stdout: keep stdout for the one JSON line
+    try:
+        ctx = gdist.init(args.gpus, backend="gloo")
+        gdist.barrier(ctx)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     a = torch.randn(64, 64)
 
     def step():
@@ -341,8 +350,19 @@ def main():
     # timing protocol (two barriers and one max-reduction of a scalar).  That runs over gloo on the host, so no collective
     # ever shares a stream with -- or is captured into -- the timed hipGraph; RCCL over xGMI is what the training harness
     # (harness/train.py: DistributedDataParallel, backend "nccl") uses for its gradient all-reduce.
-    ctx = gdist.init(args.gpus, backend="gloo")
-    device = torch.device("cuda", ctx.local_rank)
+    # (gloo announces its connections on stdout: keep stdout for the one JSON line)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        ctx = gdist.init(args.gpus, backend="gloo")
+        gdist.barrier(ctx)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    # (GANET_BENCH_DEVICE: development only -- several ranks on ONE GPU, to exercise the N > 1 path on a single-GPU box)
+    device = torch.device("cuda", int(os.environ.get("GANET_BENCH_DEVICE", ctx.local_rank)))
     torch.cuda.set_device(device)
     from ganet_amd import _native
     assert not _native.lib().is_simulator
