@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
   std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_bwd_streams{0};   // 1: filter gradient and data-backward of an LGA backward pass on two streams
   std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
   std::atomic<int> lga_vmcnt_safe{0};   // 1: the LDS-DMA kernels never count result stores when they wait for a staged plane (waits earlier than necessary)
   std::atomic<int> lga_segs{0};   // depth segments per tile for those kernels (0 = automatic)
@@ -93,6 +94,7 @@ void load_env_options()
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_VMCNT_SAFE", g_opt.lga_vmcnt_safe);
   geti("GANET_LGA_FG_WPS", g_opt.lga_fg_wps);
+  geti("GANET_LGA_BWD_STREAMS", g_opt.lga_bwd_streams);
   geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
@@ -659,6 +661,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : (value > 3 ? 3 : value);
   else if (!strcmp(name, "GANET_LGA_VMCNT_SAFE")) g_opt.lga_vmcnt_safe = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_FG_WPS")) g_opt.lga_fg_wps = value == 2 ? 2 : 3;
+  else if (!strcmp(name, "GANET_LGA_BWD_STREAMS")) g_opt.lga_bwd_streams = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
@@ -913,10 +916,25 @@ GA_EXPORT int ganet_lga_backward(const float *x, const float *f, const float *gy
   const int acc = accumulate_gf ? 1 : 0;
   // filter gradient first: it is the only consumer of x, so gx may alias x afterwards
   // (the reference's chained LGA2/LGA3 backward relies on that, functions/GANet.py:197).
-  if (radius == 1) { GA_TRY(launch_lga_gf<1>(x, gy, gf, B, D, H, W, acc, st)); return launch_lga_fwd<1>(gy, f, gx, B, D, H, W, true, st); }
-  if (radius == 2) { GA_TRY(launch_lga_gf<2>(x, gy, gf, B, D, H, W, acc, st)); return launch_lga_fwd<2>(gy, f, gx, B, D, H, W, true, st); }
-  GA_TRY(launch_lga_gf<3>(x, gy, gf, B, D, H, W, acc, st));
-  return launch_lga_fwd<3>(gy, f, gx, B, D, H, W, true, st);
+  // GANET_LGA_BWD_STREAMS=1: the two kernels of the pass are independent unless gx aliases x; each fills only ~3/4 of the
+  // chip's wave slots (2,400 single-wave workgroups on 3,072 slots at 240x624), so they may share it on two streams.
+  hipStream_t st_gf = st;
+  SidePool *pool = nullptr;
+  if (opts().lga_bwd_streams && gx != x) {
+    GA_TRY(get_pool(&pool));
+    GA_HIP(hipEventRecord(pool->fork, st));
+    GA_HIP(hipStreamWaitEvent(pool->s[0], pool->fork, 0));
+    st_gf = pool->s[0];
+  }
+  int rc;
+  if (radius == 1) { rc = launch_lga_gf<1>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<1>(gy, f, gx, B, D, H, W, true, st); }
+  else if (radius == 2) { rc = launch_lga_gf<2>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<2>(gy, f, gx, B, D, H, W, true, st); }
+  else { rc = launch_lga_gf<3>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<3>(gy, f, gx, B, D, H, W, true, st); }
+  if (pool) {
+    GA_HIP(hipEventRecord(pool->join[0], pool->s[0]));
+    GA_HIP(hipStreamWaitEvent(st, pool->join[0], 0));
+  }
+  return rc;
 }
 
 GA_EXPORT int ganet_cost_volume_forward(const float *x, const float *y, float *cost, int N, int C,

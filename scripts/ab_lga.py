@@ -34,14 +34,16 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-variants = [dict(GANET_LGA_WAVE=2), dict(GANET_LGA_WAVE=3), dict(GANET_LGA_WAVE=3, GANET_LGA_FG_WPS=2),
+variants = [dict(GANET_LGA_WAVE=2), dict(GANET_LGA_WAVE=3), dict(GANET_LGA_WAVE=3, GANET_LGA_BWD_STREAMS=1), dict(GANET_LGA_WAVE=3, GANET_LGA_FG_WPS=2),
+            dict(GANET_LGA_WAVE=3, GANET_LGA_FG_WPS=2, GANET_LGA_BWD_STREAMS=1),
             dict(GANET_LGA_WAVE=3, GANET_LGA_VMCNT_SAFE=1),
             dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=1), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=2), dict(GANET_LGA_WAVE=3, GANET_LGA_SEGS=3)]
 base = None
 for rep in range(2):
     for v in variants:
-        for k in ("GANET_LGA_WAVE", "GANET_LGA_SEGS", "GANET_LGA_SPLIT", "GANET_LGA_VMCNT_SAFE", "GANET_LGA_FG_WPS"):
-            lib.set_option(k, {"GANET_LGA_WAVE": 2, "GANET_LGA_SEGS": 0, "GANET_LGA_SPLIT": 1, "GANET_LGA_VMCNT_SAFE": 0, "GANET_LGA_FG_WPS": 3}[k])
+        for k in ("GANET_LGA_WAVE", "GANET_LGA_SEGS", "GANET_LGA_SPLIT", "GANET_LGA_VMCNT_SAFE", "GANET_LGA_FG_WPS", "GANET_LGA_BWD_STREAMS"):
+            lib.set_option(k, {"GANET_LGA_WAVE": 2, "GANET_LGA_SEGS": 0, "GANET_LGA_SPLIT": 1, "GANET_LGA_VMCNT_SAFE": 0, "GANET_LGA_FG_WPS": 3,
+                               "GANET_LGA_BWD_STREAMS": 0}[k])
         for k, val in v.items():
             lib.set_option(k, val)
         y, gx, gf = torch.empty_like(x), torch.empty_like(x), torch.empty_like(f)
