@@ -48,6 +48,7 @@ _PROTOS = {
     "ganet_trilinear_upsample_forward": [_P] * 2 + [_I] * 7 + [_P],
     "ganet_trilinear_upsample_backward": [_P] * 2 + [_I] * 7 + [_P],
     "ganet_selftest_dpp": [_P, _P, _P],
+    "ganet_selftest_dpp_wave": [_P, _P, _P],
 }
 EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])
 

@@ -126,7 +126,11 @@ enum : int {
   DPP_ROW_SHL1 = 0x101,
   DPP_ROW_SHR1 = 0x111,
   DPP_ROW_MIRROR = 0x140,
-  DPP_ROW_HALF_MIRROR = 0x141
+  DPP_ROW_HALF_MIRROR = 0x141,
+  // whole-wavefront shifts (gfx9 family incl. gfx950; gone in gfx10+): lane i <- lane i+1 / i-1 across the 16-lane rows;
+  // the first / last lane of the WAVE has no source and keeps `old`.  Used by the 64-lanes-per-scanline scans.
+  DPP_WAVE_SHL1 = 0x130,
+  DPP_WAVE_SHR1 = 0x138
 };
 
 #if !defined(GA_HIPSIM) && defined(GA_NO_DPP)
@@ -140,6 +144,8 @@ template <int CTRL> GA_DEV int dpp_src_lane(int lane, bool &valid)
   if (CTRL == DPP_ROW_SHL1) { valid = r < 15; return lane + 1; }
   if (CTRL == DPP_ROW_SHR1) { valid = r > 0; return lane - 1; }
   if (CTRL == DPP_ROW_MIRROR) return row + (15 - r);
+  if (CTRL == DPP_WAVE_SHL1) { valid = lane < 63; return lane + 1; }
+  if (CTRL == DPP_WAVE_SHR1) { valid = lane > 0; return lane - 1; }
   /* DPP_ROW_HALF_MIRROR */ return (lane & ~7) + (7 - (lane & 7));
 }
 template <int CTRL> GA_DEV int dpp_i(int old, int src)
@@ -172,12 +178,23 @@ GA_DEV float i2f(int i) { union { float f; int i; } u; u.i = i; return u.f; }
 template <int CTRL> GA_DEV float dpp_f(float old, float src) { return i2f(dpp_i<CTRL>(f2i(old), f2i(src))); }
 template <int CTRL> GA_DEV float dpp_perm_f(float src) { return i2f(dpp_perm_i<CTRL>(f2i(src))); }
 
-// ---- segment ops: a "segment" is GD consecutive lanes (GD in 1,2,4,8,16) that
+// value held by lane `l` of the wavefront, as a wave-uniform scalar
+GA_DEV float wave_readlane_f(float v, int l)
+{
+#if defined(GA_HIPSIM)
+  return i2f(hipsim::readlane(f2i(v), l));
+#else
+  return i2f(__builtin_amdgcn_readlane(f2i(v), l));
+#endif
+}
+
+// ---- segment ops: a "segment" is GD consecutive lanes (GD in 1,2,4,8,16, or the whole wave: 64) that
 // together own one scanline; lg = lane % GD.
 // value held by the previous / next lane of the segment; segment ends keep `old`
 template <int GD> GA_DEV float seg_from_prev(float old, float src, int lg)
 {
   if (GD == 1) return old;
+  if (GD == 64) return dpp_f<DPP_WAVE_SHR1>(old, src);     // the wave IS the segment: lane 0 has no source and keeps `old`
   const float r = dpp_f<DPP_ROW_SHR1>(old, src);
   if (GD == 16) return r;          // a 16-lane segment IS a DPP row: its lane 0 has no source and keeps `old`
   return lg == 0 ? old : r;
@@ -185,6 +202,7 @@ template <int GD> GA_DEV float seg_from_prev(float old, float src, int lg)
 template <int GD> GA_DEV float seg_from_next(float old, float src, int lg)
 {
   if (GD == 1) return old;
+  if (GD == 64) return dpp_f<DPP_WAVE_SHL1>(old, src);
   const float r = dpp_f<DPP_ROW_SHL1>(old, src);
   if (GD == 16) return r;
   return lg == GD - 1 ? old : r;
@@ -218,6 +236,10 @@ template <int GD> GA_DEV float seg_allmax(float v)
   if (GD >= 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
   if (GD >= 16) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
 #endif
+  if (GD == 64) {     // every lane of a row now holds the row's maximum: combine the four rows through scalars
+    const float r0 = wave_readlane_f(v, 0), r1 = wave_readlane_f(v, 16), r2 = wave_readlane_f(v, 32), r3 = wave_readlane_f(v, 48);
+    v = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+  }
   return v;
 }
 template <int GD> GA_DEV float seg_allsum(float v)
@@ -226,6 +248,10 @@ template <int GD> GA_DEV float seg_allsum(float v)
   if (GD >= 4) v += dpp_perm_f<DPP_QP_XOR2>(v);
   if (GD >= 8) v += dpp_perm_f<DPP_ROW_HALF_MIRROR>(v);
   if (GD >= 16) v += dpp_perm_f<DPP_ROW_MIRROR>(v);
+  if (GD == 64) {
+    const float r0 = wave_readlane_f(v, 0), r1 = wave_readlane_f(v, 16), r2 = wave_readlane_f(v, 32), r3 = wave_readlane_f(v, 48);
+    v = (r0 + r1) + (r2 + r3);
+  }
   return v;
 }
 // (max value, smallest index attaining it) over the segment: the reference's

@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
   std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> wide_scan{1};    // SGA scans with the whole wavefront on one scanline: 1 for inputs with few scanlines (and D > 272), 0 never, 2 whenever D > 48 (tests)
   std::atomic<int> lga_bwd_streams{0};   // 1: filter gradient and data-backward of an LGA backward pass on two streams
   std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
   std::atomic<int> lga_vmcnt_safe{0};   // 1: the LDS-DMA kernels never count result stores when they wait for a staged plane (waits earlier than necessary)
@@ -95,6 +96,7 @@ void load_env_options()
   geti("GANET_LGA_VMCNT_SAFE", g_opt.lga_vmcnt_safe);
   geti("GANET_LGA_FG_WPS", g_opt.lga_fg_wps);
   geti("GANET_LGA_BWD_STREAMS", g_opt.lga_bwd_streams);
+  geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
@@ -140,8 +142,10 @@ int get_pool(SidePool **out)
 
 // ---- SGA kernel selection -----------------------------------------------------------
 // (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
+// GD = 64: the whole wavefront owns one scanline (D up to 1,088; 4x the waves of GD = 16 for inputs with few scanlines)
 #define GA_SGA_PAIRS(X) \
-  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 5) X(4, 9) X(4, 17)
+  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 5) X(4, 9) X(4, 17) \
+  X(64, 3) X(64, 5) X(64, 9) X(64, 17)
 
 constexpr int fwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
 constexpr int fwd_nv(int dpl) { return dpl <= 5 ? 2 : 1; }
@@ -158,7 +162,8 @@ bool pick_pair(int D, int want_gd, int *gd, int *dpl)
   }
   GA_SGA_PAIRS(X)
 #undef X
-  if (best_gd == 0 && want_gd != 16) return pick_pair(D, 16, gd, dpl);
+  if (best_gd == 0 && want_gd != 16 && want_gd != 64) return pick_pair(D, 16, gd, dpl);
+  if (best_gd == 0 && want_gd == 16) return pick_pair(D, 64, gd, dpl);      // D > 272: wave-wide scanlines
   if (best_gd == 0) return false;
   *gd = best_gd;
   *dpl = best_dpl;
@@ -230,15 +235,15 @@ int launch_scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, co
   return check_launch("sga adjoint scan");
 }
 
-// float-valued mask (reference buffer contract): element-strided traversal, GD = 16 family
-template <int DPL>
+// float-valued mask (reference buffer contract): element-strided traversal, GD = 16 family (64 for D > 272)
+template <int GD, int DPL>
 int launch_scan_bwdg_f32mask(const float *g, const float *mask, const uint16_t *kp, const float *gout,
                              float *G, int S, int D, int H, int W, int dir, hipStream_t st)
 {
   ScanGeom geo = make_geom(S, D, H, W, dir, true);
-  const int block = 64, lpb = block / 16;
+  const int block = 64, lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
-  GA_LAUNCH((sga_bwdg_strided<16, DPL, bwd_sb(DPL), float>), dim3(grid), dim3(block), st, g, mask, kp,
+  GA_LAUNCH((sga_bwdg_strided<GD, DPL, bwd_sb(DPL), float>), dim3(grid), dim3(block), st, g, mask, kp,
             gout, G, geo, dir);
   return check_launch("sga adjoint scan (f32 mask)");
 }
@@ -351,16 +356,43 @@ int row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const floa
   return check_launch("sga row adjoint scan");
 }
 
+int device_cus();
+
+// Inputs with few scanlines (a single slice at full resolution: SURVEY 8d's literal stress shape [1,1,192,240,624] has 624
+// columns / 240 rows) leave most of the 1,024 SIMDs without a wave when a scanline is 16 lanes wide (156 / 240 waves): the
+// segment kernels with the whole wavefront on one scanline give 4x the waves and a quarter of the serial work per position.
+// Measured on that shape (profiles/r2n_sga_wide_scan_stress_shape.txt): horizontal scans 0.25 -> 0.10 ms forward and
+// 0.31 -> 0.21 ms adjoint; VERTICAL scans do not gain (0.33 -> 0.32, adjoint 0.49 -> 0.54-0.64 ms): with one column per wave
+// every lane of a load touches a different plane (64 cache lines for 256 bytes), which the LDS-staged column blocks avoid.
+// So the automatic mode widens horizontal scans only; D > 272 takes the wide kernels in every direction (pick_pair).
+bool few_lines(int N, int C, int D, int H, int W, int dir)
+{
+  if (opts().wide_scan == 0) return false;
+  if (opts().wide_scan == 2) return D > 48;
+  if (dir < 2) return false;
+  const i64 lines = (i64)N * C * H;
+  return D >= 96 && lines * 16 < (i64)4 * device_cus() * 64 * 2;      // fewer 16-lane segments than two waves per SIMD hold
+}
+
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
              hipStream_t st)
 {
+  if (few_lines(N, C, D, H, W, dir)) {
+    int gd, dpl;
+    if (pick_pair(D, 64, &gd, &dpl)) {
+#define X(G, P) \
+      if ((G) == 64 && dpl == (P)) return launch_scan_fwd<G, P>(x, g, A, N * C, D, H, W, dir, st);
+      GA_SGA_PAIRS(X)
+#undef X
+    }
+  }
   if (rowwave_ok(D, W, dir, row_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A))
     return row_fwd(x, g, A, N * C, D, H, W, dir, st);
   if (colblock_ok(D, W, dir, col_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A) && N * C <= 65535)
     return col_fwd(x, g, A, N * C, D, H, W, dir, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
-    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (1088)", D);
 #define X(G, P) \
   if (gd == (G) && dpl == (P)) return launch_scan_fwd<G, P>(x, g, A, N * C, D, H, W, dir, st);
   GA_SGA_PAIRS(X)
@@ -371,6 +403,15 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
 int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
               int N, int C, int D, int H, int W, int dir, hipStream_t st)
 {
+  if (few_lines(N, C, D, H, W, dir)) {
+    int gd, dpl;
+    if (pick_pair(D, 64, &gd, &dpl)) {
+#define X(G_, P) \
+      if ((G_) == 64 && dpl == (P)) return launch_scan_bwdg<G_, P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
+      GA_SGA_PAIRS(X)
+#undef X
+    }
+  }
   if (rowwave_ok(D, W, dir, row_smem_bwdg(D)) && aligned16(g) && aligned16(gout) && aligned16(G) &&
       (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0))
     return row_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
@@ -379,7 +420,7 @@ int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const flo
     return col_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   int gd, dpl;
   if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
-    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (1088)", D);
 #define X(G_, P) \
   if (gd == (G_) && dpl == (P)) return launch_scan_bwdg<G_, P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   GA_SGA_PAIRS(X)
@@ -392,9 +433,9 @@ int scan_bwdg_f32mask(const float *g, const float *mask, const uint16_t *kp, con
 {
   int gd, dpl;
   if (!pick_pair(D, 16, &gd, &dpl))
-    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (272)", D);
+    return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (1088)", D);
 #define X(G_, P) \
-  if ((G_) == 16 && dpl == (P)) return launch_scan_bwdg_f32mask<P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
+  if (((G_) == 16 || (G_) == 64) && gd == (G_) && dpl == (P)) return launch_scan_bwdg_f32mask<G_, P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   GA_SGA_PAIRS(X)
 #undef X
   return fail(GANET_E_UNSUPPORTED, "SGA: no kernel for DPL=%d", dpl);
@@ -635,6 +676,16 @@ __global__ void dpp_probe(int *out)
   out[7 * 64 + lane] = (int)seg_allsum<16>((float)lane);
 }
 
+// whole-wavefront patterns of the 64-lanes-per-scanline scans
+__global__ void dpp_probe_wave(int *out)
+{
+  const int lane = threadIdx.x;
+  out[0 * 64 + lane] = dpp_i<DPP_WAVE_SHL1>(-1, lane);
+  out[1 * 64 + lane] = dpp_i<DPP_WAVE_SHR1>(-1, lane);
+  out[2 * 64 + lane] = (int)seg_allmax<64>((float)((lane * 37) % 64));
+  out[3 * 64 + lane] = (int)seg_allsum<64>((float)lane);
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -662,6 +713,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_VMCNT_SAFE")) g_opt.lga_vmcnt_safe = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_FG_WPS")) g_opt.lga_fg_wps = value == 2 ? 2 : 3;
   else if (!strcmp(name, "GANET_LGA_BWD_STREAMS")) g_opt.lga_bwd_streams = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
@@ -1151,6 +1203,33 @@ GA_EXPORT int ganet_softmin_regression_backward(const float *x, const float *out
   GA_LAUNCH(softmin_regression_bwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, out, mx, ssum,
             grad_out, grad_x, N, Dn, HW);
   return check_launch("softmin regression backward");
+}
+
+GA_EXPORT int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream)
+{
+  if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp_wave: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GA_LAUNCH(dpp_probe_wave, dim3(1), dim3(64), st, scratch_dev);
+  GA_TRY(check_launch("dpp probe (wave)"));
+#if defined(GA_HIPSIM)
+  memcpy(host_out, scratch_dev, sizeof(int) * 4 * 64);
+#else
+  GA_HIP(hipMemcpyAsync(host_out, scratch_dev, sizeof(int) * 4 * 64, hipMemcpyDeviceToHost, st));
+  GA_HIP(hipStreamSynchronize(st));
+#endif
+  int bad = 0, first_pat = -1, first_lane = -1;
+  for (int lane = 0; lane < 64; lane++) {
+    const int expect[4] = {lane < 63 ? lane + 1 : -1, lane > 0 ? lane - 1 : -1, 63, 2016};
+    for (int p = 0; p < 4; p++)
+      if (host_out[p * 64 + lane] != expect[p]) {
+        if (!bad) { first_pat = p; first_lane = lane; }
+        bad++;
+      }
+  }
+  if (bad)
+    return fail(GANET_E_RUNTIME, "DPP self-test (wave): %d mismatches, first at pattern %d lane %d (got %d)",
+                bad, first_pat, first_lane, host_out[first_pat * 64 + first_lane]);
+  return GANET_OK;
 }
 
 GA_EXPORT int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream)

@@ -220,11 +220,16 @@ int ganet_trilinear_upsample_backward(const float *grad_y, float *grad_x, int S,
  * (host memory, >= 8*64 ints) receives the raw lane values.  Synchronises `stream`.
  * Returns 0 if all patterns match. */
 int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
+/* The same for the whole-wavefront patterns of the 64-lanes-per-scanline scans (wave_shl:1, wave_shr:1, the wave-wide
+ * maximum and sum); scratch / host_out: >= 4*64 ints. */
+int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
 
 /* Tuning knobs (also read from the environment at first use):
  *   GANET_SGA_GD_V / GANET_SGA_GD_H = 4|8|16  lanes per scanline, vertical / horizontal scans
  *                         (defaults 4 / 16; GANET_SGA_GD sets both through ganet_set_option)
  *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
+ *   GANET_SGA_WIDE_SCAN=0|1|2  scans with the whole wavefront on one scanline: never | for inputs with few scanlines and for
+ *                         D > 272 (default) | whenever D > 48
  *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans (segment kernels)
  *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: segment kernels)
  *   GANET_SGA_MERGE4 = 0|1  four-pixels-per-lane merge + arg-max (default 1)

@@ -11,7 +11,7 @@
 // thread; __syncthreads() and the DPP exchange are generation barriers that yield
 // to a round-robin scheduler.  Wavefront = 64 consecutive threads.  DPP follows
 // the gfx9 ISA: quad_perm, row_shl/shr:n, row_mirror, row_half_mirror within
-// 16-lane rows; a lane whose source is out of range keeps `old`.
+// 16-lane rows, wave_shl:1 / wave_shr:1 across the wavefront; a lane whose source is out of range keeps `old`.
 #pragma once
 #include <assert.h>
 #include <math.h>
@@ -107,11 +107,26 @@ inline int update_dpp(int old, int src, int ctrl)
   if (ctrl >= 0 && ctrl <= 0xFF) sl = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
   else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int r = (lane & 15) + (ctrl - 0x100); valid = r < 16; sl = (lane & ~15) + r; }
   else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int r = (lane & 15) - (ctrl - 0x110); valid = r >= 0; sl = (lane & ~15) + r; }
+  else if (ctrl == 0x130) { valid = lane < 63; sl = lane + 1; }     // wave_shl:1
+  else if (ctrl == 0x138) { valid = lane > 0; sl = lane - 1; }      // wave_shr:1
   else if (ctrl == 0x140) sl = (lane & ~15) + (15 - (lane & 15));
   else if (ctrl == 0x141) sl = (lane & ~7) + (7 - (lane & 7));
   else { fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
   if (valid && sl >= wsize) valid = false;   // inactive source lane: dest keeps old
   const int v = valid ? s.xchg[wave * 64 + sl] : old;
+  barrier_wait(s.wave_bar[wave], wsize);
+  return v;
+}
+
+// v_readlane_b32: the value lane `l` of the caller's wavefront holds
+inline int readlane(int src, int l)
+{
+  State &s = S();
+  const int tid = flat_tid(), wave = tid >> 6;
+  const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
+  s.xchg[tid] = src;
+  barrier_wait(s.wave_bar[wave], wsize);
+  const int v = s.xchg[wave * 64 + (l < wsize ? l : 0)];
   barrier_wait(s.wave_bar[wave], wsize);
   return v;
 }

@@ -63,6 +63,7 @@ def test_dpp_lane_patterns(api, dev):
     scratch = dev.zeros((8 * 64,), np.int32)
     host = np.zeros(8 * 64, np.int32)
     api.call("ganet_selftest_dpp", scratch.data_ptr(), host.ctypes.data, dev.stream)
+    api.call("ganet_selftest_dpp_wave", scratch.data_ptr(), host.ctypes.data, dev.stream)     # wave_shl / wave_shr / readlane
 
 
 @pytest.mark.parametrize("name", sga_case_names())
@@ -453,3 +454,18 @@ def test_lga_dma_wait_modes_and_kernel_families(api, dev, port_oracle, shape, se
         ogx, ogf = port_oracle.lga_chain_backward(ins, f.cpu().numpy(), gy.cpu().numpy(), 2)
         for got, want in zip(res["pp"], (y, ogx, ogf)):
             assert np.abs(got.cpu().numpy() - want).max() <= pc.TOL
+
+
+@pytest.mark.parametrize("shape,wide", [((1, 1, 300, 5, 12), 1), ((1, 2, 577, 3, 8), 1), ((1, 2, 65, 9, 24), 2), ((1, 1, 193, 4, 20), 2),
+                                        ((1, 1, 192, 240, 624), 1)])
+def test_sga_wave_wide_scanlines_vs_oracle(api, dev, port_oracle, shape, wide):
+    """Scans with the whole wavefront on one scanline (GANET_SGA_WIDE_SCAN): D beyond the 16-lane limit of 272, forced
+    on ordinary volumes, and chosen automatically for SURVEY 8d's literal stress shape [1,1,192,240,624] (one slice: 624
+    columns / 240 rows).  Same bar as everywhere: forward / mask / arg-max bit-exact, gradients within 1e-4."""
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    api.set_option("GANET_SGA_WIDE_SCAN", wide)
+    try:
+        err = pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go), per_dir=shape[3] < 100)
+    finally:
+        api.set_option("GANET_SGA_WIDE_SCAN", 1)
+    print("wide scan", shape, err)

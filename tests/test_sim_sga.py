@@ -103,14 +103,15 @@ def test_dpp_selftest(sim):
     scratch = np.zeros(8 * 64, np.int32)
     host = np.zeros(8 * 64, np.int32)
     sim.call("ganet_selftest_dpp", scratch.ctypes.data, host.ctypes.data, None)
+    sim.call("ganet_selftest_dpp_wave", scratch.ctypes.data, host.ctypes.data, None)
 
 
 def test_errors_are_reported(sim):
     from ganet_amd._native import GanetError
-    x = np.zeros((1, 1, 300, 1, 1), np.float32)
+    x = np.zeros((1, 1, 1100, 1, 1), np.float32)
     g = np.zeros((1, 1, 5, 1, 1), np.float32)
-    with pytest.raises(GanetError, match="exceeds"):
-        sim.call("ganet_sga_scan_forward", x.ctypes.data, g.ctypes.data, x.ctypes.data, 1, 1, 300, 1, 1, 0, None)
+    with pytest.raises(GanetError, match="exceeds"):          # 64 lanes x 17 disparities = 1,088 is the compiled maximum
+        sim.call("ganet_sga_scan_forward", x.ctypes.data, g.ctypes.data, x.ctypes.data, 1, 1, 1100, 1, 1, 0, None)
     with pytest.raises(GanetError, match="null"):
         sim.call("ganet_sga_scan_forward", None, g.ctypes.data, x.ctypes.data, 1, 1, 3, 1, 1, 0, None)
     with pytest.raises(GanetError, match="dir"):
@@ -124,3 +125,23 @@ def test_forward_backward_vs_oracle_float4_rows(sim, port_oracle, shape):
     x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
     err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
     assert max(err.values()) < 2e-5, err
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 65, 5, 12), (1, 2, 193, 3, 8), (1, 1, 300, 3, 4), (1, 1, 49, 4, 7), (1, 1, 577, 2, 4)])
+def test_wave_wide_scanlines(sim, port_oracle, shape):
+    """GANET_SGA_WIDE_SCAN=2: the segment kernels with the WHOLE wavefront on one scanline (wave_shl / wave_shr DPP across the
+    16-lane rows, row maxima / sums combined through v_readlane) -- what inputs with few scanlines and D > 272 use.
+    Forward volumes / mask / arg-max bit-exact, gradients within 1e-4, including D = 300 and 577 (beyond the 16-lane limit)."""
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    out, tmp, mask = port_oracle.sga_forward(x, *gs)
+    grads = port_oracle.sga_backward(x, *gs, tmp, mask, go)
+    want = {"out": out, "mask": mask.astype(np.uint8), "tmp": tmp, "gx": grads[0]}
+    for d in range(4):
+        want[f"gw{d}"] = grads[1 + d]
+    sim.set_option("GANET_SGA_WIDE_SCAN", 2)
+    try:
+        pc.check_sga_forward_backward(sim, DEV, x, gs, go, want)
+        if shape[2] in (300, 49):
+            pc.check_sga_compat(sim, DEV, x, gs, go, want)          # reference buffer contract (float mask) as well
+    finally:
+        sim.set_option("GANET_SGA_WIDE_SCAN", 1)
