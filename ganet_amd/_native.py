@@ -54,7 +54,14 @@ EXPORTS = sorted(list(_PROTOS) + ["ganet_last_error"])
 
 
 class GanetError(RuntimeError):
-    pass
+    """A C-ABI entry returned a negative code (GANET_E_INVALID -1, GANET_E_UNSUPPORTED -2, GANET_E_RUNTIME -3)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+E_INVALID, E_UNSUPPORTED, E_RUNTIME = -1, -2, -3
 
 
 class CApi:
@@ -84,13 +91,13 @@ class CApi:
     def call(self, name, *args):
         rc = getattr(self._lib, name)(*args)
         if rc != 0:
-            raise GanetError(f"{name} failed ({rc}): {self.last_error()}")
+            raise GanetError(f"{name} failed ({rc}): {self.last_error()}", rc)
 
     def query(self, name, *args):
         """entry points that answer with a non-negative number"""
         rc = getattr(self._lib, name)(*args)
         if rc < 0:
-            raise GanetError(f"{name} failed ({rc}): {self.last_error()}")
+            raise GanetError(f"{name} failed ({rc}): {self.last_error()}", rc)
         return rc
 
     def set_option(self, name, value):

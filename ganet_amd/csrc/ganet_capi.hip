@@ -564,7 +564,8 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
       if constexpr (R <= 2) if (items_pp < (1ll << 31)) {
         if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
         else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        if (getenv("GANET_TRACE_DISPATCH")) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d split=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg, sg.split_a);
+        static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
+        if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d split=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg, sg.split_a);
         return check_launch("lga apply (plane pairs)");
       }
     }

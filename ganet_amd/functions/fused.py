@@ -236,7 +236,7 @@ class LgaRegressFunction(Function):
                 snorm.clamp_(min=1e-12)
                 out = sdy / snorm
             except _native.GanetError as e:                # no fused kernel for this shape: the two separate entries
-                if "no fused kernel" not in str(e):
+                if e.code != _native.E_UNSUPPORTED:
                     raise
                 y = torch.empty_like(x)
                 out = sdy
