@@ -1167,7 +1167,10 @@ GA_EXPORT int ganet_softmin_forward(const float *x, float *y, int N, int Dn, int
   if (!x || !y) return fail(GANET_E_INVALID, "ganet_softmin_forward: null pointer");
   if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0) return fail(GANET_E_INVALID, "ganet_softmin_forward: non-positive size");
   const i64 HW = (i64)H * W;
-  GA_LAUNCH(softmin_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, y, N, Dn, HW);
+  if (HW % 4 == 0 && aligned16(x) && aligned16(y))
+    GA_LAUNCH(softmin_fwd4, dim3(ew_grid((i64)N * HW / 4)), dim3(256), (hipStream_t)stream, x, y, N, Dn, HW);
+  else
+    GA_LAUNCH(softmin_fwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, x, y, N, Dn, HW);
   return check_launch("softmin forward");
 }
 
@@ -1177,7 +1180,10 @@ GA_EXPORT int ganet_softmin_backward(const float *y, const float *grad_y, float 
   if (!y || !grad_y || !grad_x) return fail(GANET_E_INVALID, "ganet_softmin_backward: null pointer");
   if (N <= 0 || Dn <= 0 || H <= 0 || W <= 0) return fail(GANET_E_INVALID, "ganet_softmin_backward: non-positive size");
   const i64 HW = (i64)H * W;
-  GA_LAUNCH(softmin_bwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, y, grad_y, grad_x, N, Dn, HW);
+  if (HW % 4 == 0 && aligned16(y) && aligned16(grad_y) && aligned16(grad_x))
+    GA_LAUNCH(softmin_bwd4, dim3(ew_grid((i64)N * HW / 4)), dim3(256), (hipStream_t)stream, y, grad_y, grad_x, N, Dn, HW);
+  else
+    GA_LAUNCH(softmin_bwd, dim3(ew_grid((i64)N * HW)), dim3(256), (hipStream_t)stream, y, grad_y, grad_x, N, Dn, HW);
   return check_launch("softmin backward");
 }
 

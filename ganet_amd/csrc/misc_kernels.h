@@ -429,6 +429,100 @@ softmin_bwd(const float *__restrict__ y, const float *__restrict__ gy, float *__
   }
 }
 
+// Four consecutive pixels per lane (16-byte requests, HW % 4 == 0, 16-byte aligned volumes): the same two walks.  The
+// one-pixel forms above issue 4-byte requests, which reach ~2 TB/s on this chip against ~4.5 TB/s for 16-byte ones
+// (scripts/ubench/stream_patterns.hip) -- and these kernels are pure streaming.
+static __global__ void __launch_bounds__(256)
+softmin_fwd4(const float *__restrict__ x, float *__restrict__ y, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * (HW >> 2);
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / (HW >> 2), pix = (o - n * (HW >> 2)) << 2;
+    const float *xp = x + n * Dn * HW + pix;
+    float *yp = y + n * Dn * HW + pix;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, ssum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < Dn; d0 += 4) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f4 *>(xp + (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float mc = m[j];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (d0 + u < Dn) mc = fmaxf(mc, -f4_get(v[u], j));
+        ssum[j] *= expf(m[j] - mc);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (d0 + u < Dn) ssum[j] += expf(-f4_get(v[u], j) - mc);
+        m[j] = mc;
+      }
+    }
+    float inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) inv[j] = 1.f / ssum[j];
+    for (int d0 = 0; d0 < Dn; d0 += 4) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f4 *>(xp + (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (d0 + u < Dn) {
+          f4 r;
+          r.x = expf(-v[u].x - m[0]) * inv[0]; r.y = expf(-v[u].y - m[1]) * inv[1];
+          r.z = expf(-v[u].z - m[2]) * inv[2]; r.w = expf(-v[u].w - m[3]) * inv[3];
+          *reinterpret_cast<f4 *>(yp + (i64)(d0 + u) * HW) = r;
+        }
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256)
+softmin_bwd4(const float *__restrict__ y, const float *__restrict__ gy, float *__restrict__ gx, int N, int Dn, i64 HW)
+{
+  const i64 total = (i64)N * (HW >> 2);
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const i64 n = o / (HW >> 2), pix = (o - n * (HW >> 2)) << 2;
+    const float *yp = y + n * Dn * HW + pix, *gp = gy + n * Dn * HW + pix;
+    float *gxp = gx + n * Dn * HW + pix;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < Dn; d0 += 4) {
+      f4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const i64 off = (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW;
+        a[u] = *reinterpret_cast<const f4 *>(yp + off);
+        b[u] = *reinterpret_cast<const f4 *>(gp + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (d0 + u < Dn) {
+          dot[0] = fmaf(a[u].x, b[u].x, dot[0]); dot[1] = fmaf(a[u].y, b[u].y, dot[1]);
+          dot[2] = fmaf(a[u].z, b[u].z, dot[2]); dot[3] = fmaf(a[u].w, b[u].w, dot[3]);
+        }
+    }
+    for (int d0 = 0; d0 < Dn; d0 += 4) {
+      f4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const i64 off = (i64)(d0 + u < Dn ? d0 + u : Dn - 1) * HW;
+        a[u] = *reinterpret_cast<const f4 *>(yp + off);
+        b[u] = *reinterpret_cast<const f4 *>(gp + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (d0 + u < Dn) {
+          f4 r;
+          r.x = -a[u].x * (b[u].x - dot[0]); r.y = -a[u].y * (b[u].y - dot[1]);
+          r.z = -a[u].z * (b[u].z - dot[2]); r.w = -a[u].w * (b[u].w - dot[3]);
+          *reinterpret_cast<f4 *>(gxp + (i64)(d0 + u) * HW) = r;
+        }
+    }
+  }
+}
+
 // out[n,h,w] = sum_d d * softmin_d(x)  (Disp.forward, models/GANet_deep.py:217-219: Softmin(dim=1) + DisparityRegression)
 // in ONE walk over the lane's column: running max m of -x with rescaled sums s = sum e^(-x-m), t = sum d e^(-x-m);
 // the probabilities are never written.  mx / ssum ([N,H,W]) are kept for the backward, which recomputes them:

@@ -115,7 +115,7 @@ def test_sga_forward_infer_bn_relu_epilogue(sim, port_oracle, shape, with_bn):
         assert np.array_equal(out, want)
 
 
-@pytest.mark.parametrize("N,D,H,W", [(1, 7, 3, 5), (2, 193, 2, 3), (1, 16, 4, 4)])
+@pytest.mark.parametrize("N,D,H,W", [(1, 7, 3, 5), (2, 193, 2, 3), (1, 16, 4, 4), (2, 193, 2, 4), (1, 5, 3, 8)])
 def test_softmin_forward_backward(sim, N, D, H, W):
     """nn.Softmin(dim=1) (models/GANet_deep.py:244) vs torch on the CPU, incl. large-magnitude inputs."""
     rng = np.random.default_rng(D)
