@@ -159,8 +159,8 @@ _FAMILY_KERNELS = {
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
                      ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false>"]],
-    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp<2, 3, 0>", "lga_apply_pp<2, true>"]],
-    "lga_apply (fwd pass)": [["lga_apply_pp<2, false>"]],
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp<2, 3, 0>", "lga_apply_pp<2, true, false>"]],
+    "lga_apply (fwd pass)": [["lga_apply_pp<2, false, false>"]],
 }
 
 
