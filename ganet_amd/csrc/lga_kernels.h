@@ -1214,7 +1214,10 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
   // steady steps q in [ql, qh): q + P a full pair inside the segment's request range; both outputs inside
   // [max(d_lo, 1), min(d_hi, D - 1))
   const int ql = ((d_lo + 2) >> 1) - m_lo;
-  int qh = npair - P;
+  // (q + P + 1 < npair: the steady body advances the request pointer unconditionally, so the pair AFTER the one it requests
+  // must exist too -- with q + P == npair - 1 the pointer would end one pair past the volume and the re-requests of the
+  // general body would read there: a fault at the end of the last batch element once a plane pair spans whole pages)
+  int qh = npair - P - 1;
   if ((D >> 1) - m_lo - P < qh) qh = (D >> 1) - m_lo - P;
   {
     const int L = d_hi < D - 1 ? d_hi : D - 1;
@@ -1489,8 +1492,12 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
       }
     }
   };
-  // steady steps: 1 <= q and 2 (q + P) + 2 <= D - 1
-  const int qh = (D - 1 - 2 * P) >> 1;
+  // steady steps: 1 <= q and 2 (q + P) + 3 <= D - 1: the steady body requests gy planes 2(q+P)+1, +2 and x pair q + P and
+  // advances its pointers unconditionally, so the NEXT plane / pair must exist as well (the general body re-requests through
+  // the same pointers; one plane past the end of the last batch element is a fault once a plane spans whole pages -- seen at
+  // 528x960, silent at 240x624)
+  int qh = (D - 2 - 2 * P) >> 1;
+  if (npair - P - 1 < qh) qh = npair - P - 1;
   int q0 = 0;
   for (; q0 < npair && q0 < 1; q0 += U) group(std::false_type{}, q0);
   for (; q0 + U <= qh; q0 += U) group(std::true_type{}, q0);

@@ -1,6 +1,9 @@
 """Parity checks shared by the CPU-emulator tests (numpy buffers, tests/hipsim) and the
 GPU tests (torch device buffers): every check drives the C ABI of include/ganet_hip.h
 and compares with the oracle / golden fixtures.  `dev` abstracts buffer handling."""
+import ctypes
+import mmap
+
 import numpy as np
 
 TOL = 1e-4   # north_star: fp32 max-abs <= 1e-4 for SGA/LGA forward + backward
@@ -19,20 +22,47 @@ def sga_inputs(shape, seed):
     return x, gs, go
 
 
+_PAGE = mmap.PAGESIZE
+_libc = ctypes.CDLL(None, use_errno=True)
+_libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+
+def guarded_empty(shape, dtype=np.float32):
+    """An array whose last byte is followed by an inaccessible page (and whose mapping is preceded by one): a kernel that
+    reads or writes past the end of a tensor -- harmless on the GPU as long as the neighbouring memory happens to be mapped,
+    a memory access fault once it is not (the 528x960 volumes of round 2) -- dies right here on the emulator."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape, dtype=np.int64))
+    nbytes = count * dtype.itemsize
+    body = -(-max(nbytes, 1) // _PAGE) * _PAGE
+    mm = mmap.mmap(-1, body + 2 * _PAGE)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+    for off in (0, _PAGE + body):
+        if _libc.mprotect(base + off, _PAGE, 0) != 0:
+            raise OSError(ctypes.get_errno(), "mprotect")
+    start = (_PAGE + body - nbytes) & ~15               # 16-byte aligned like any device allocation
+    return np.frombuffer(mm, dtype, count, start).reshape(shape)
+
+
 class NumpyDev:
-    """Host buffers for the emulator build."""
+    """Host buffers for the emulator build (every buffer ends at a guard page, see guarded_empty)."""
     stream = None
 
     def to(self, a):
-        return np.ascontiguousarray(a)
+        a = np.asarray(a)
+        g = guarded_empty(a.shape, a.dtype)
+        g[...] = a
+        return g
 
     def empty(self, shape, dtype=np.float32):
-        a = np.empty(shape, dtype)
+        a = guarded_empty(shape, dtype)
         a.fill(np.nan if dtype == np.float32 else 113)     # poison: unwritten elements get noticed
         return a
 
     def zeros(self, shape, dtype=np.float32):
-        return np.zeros(shape, dtype)
+        a = guarded_empty(shape, dtype)
+        a.fill(0)
+        return a
 
     def ptr(self, a):
         return a.ctypes.data

@@ -17,9 +17,32 @@ def sim():
     return sim_api()
 
 
-def _p(a):
-    assert a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data
+class _p:
+    """An array argument of _call."""
+
+    def __init__(self, a):
+        assert a.flags["C_CONTIGUOUS"]
+        self.a = a
+
+
+def _call(sim, name, *args):
+    """sim.call with every array argument passed as a copy that ends at a guard page (parity_cases.guarded_empty): reads or
+    writes past the end of a tensor crash here instead of depending on what the neighbouring memory is."""
+    import parity_cases as pc
+    bufs, conv = [], []
+    for v in args:
+        if isinstance(v, _p):
+            g = pc.guarded_empty(v.a.shape, v.a.dtype)
+            g[...] = v.a
+            bufs.append((v.a, g))
+            conv.append(g.ctypes.data)
+        else:
+            conv.append(v)
+    try:
+        return sim.call(name, *conv)
+    finally:
+        for a, g in bufs:
+            a[...] = g
 
 
 @pytest.mark.parametrize("N,C,H,W", [(1, 2, 3, 4), (2, 3, 5, 7), (1, 1, 1, 1)])
@@ -30,14 +53,14 @@ def test_guidance_normalize_forward_backward(sim, N, C, H, W):
     g[0, 7, 0, 0] = 0.0                                    # sgn(0) = 0
     gys = [rng.standard_normal((N, C, 5, H, W)).astype(np.float32) for _ in range(4)]
     ys = [np.full((N, C, 5, H, W), np.nan, np.float32) for _ in range(4)]
-    sim.call("ganet_l1_normalize_forward", _p(g), *[_p(y) for y in ys], N, 4, C, 5, H, W, None)
+    _call(sim, "ganet_l1_normalize_forward", _p(g), *[_p(y) for y in ys], N, 4, C, 5, H, W, None)
     tg = torch.from_numpy(g).requires_grad_()
     want = fr.sgablock_guidance(tg, C)
     for y, w in zip(ys, want):
         np.testing.assert_allclose(y, w.detach().numpy(), rtol=RTOL, atol=ATOL)
     torch.autograd.backward(want, [torch.from_numpy(a) for a in gys])
     gx = np.full_like(g, np.nan)
-    sim.call("ganet_l1_normalize_backward", _p(g), *[_p(a) for a in gys], _p(gx), N, 4, C, 5, H, W, None)
+    _call(sim, "ganet_l1_normalize_backward", _p(g), *[_p(a) for a in gys], _p(gx), N, 4, C, 5, H, W, None)
     wg = tg.grad.numpy()
     ok = np.abs(wg) < 1e6                                  # (clamped group: gradient = gy / 1e-12, compare relatively)
     np.testing.assert_allclose(gx[ok], wg[ok], rtol=1e-4, atol=1e-5)
@@ -51,13 +74,13 @@ def test_filter_normalize_any_K(sim, K):
     g = rng.standard_normal((N, K, H, W)).astype(np.float32)
     gy = rng.standard_normal((N, K, H, W)).astype(np.float32)
     y = np.full_like(g, np.nan)
-    sim.call("ganet_l1_normalize_forward", _p(g), _p(y), None, None, None, N, 1, 1, K, H, W, None)
+    _call(sim, "ganet_l1_normalize_forward", _p(g), _p(y), None, None, None, N, 1, 1, K, H, W, None)
     tg = torch.from_numpy(g).requires_grad_()
     want = fr.lga_filters(tg)
     np.testing.assert_allclose(y, want.detach().numpy(), rtol=RTOL, atol=ATOL)
     want.backward(torch.from_numpy(gy))
     gx = np.full_like(g, np.nan)
-    sim.call("ganet_l1_normalize_backward", _p(g), _p(gy), None, None, None, _p(gx), N, 1, 1, K, H, W, None)
+    _call(sim, "ganet_l1_normalize_backward", _p(g), _p(gy), None, None, None, _p(gx), N, 1, 1, K, H, W, None)
     np.testing.assert_allclose(gx, tg.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
@@ -71,14 +94,14 @@ def test_norm_disparity_regression(sim, N, maxdisp, H, W):
     go = rng.standard_normal((N, H, W)).astype(np.float32)
     out = np.full((N, H, W), np.nan, np.float32)
     sn = np.full((N, H, W), np.nan, np.float32)
-    sim.call("ganet_norm_disparity_regression_forward", _p(x), _p(out), _p(sn), N, D, H, W, None)
+    _call(sim, "ganet_norm_disparity_regression_forward", _p(x), _p(out), _p(sn), N, D, H, W, None)
     tx = torch.from_numpy(x).requires_grad_()
     want = fr.norm_regression(tx, maxdisp)
     np.testing.assert_allclose(out, want.detach().numpy(), rtol=1e-5, atol=1e-4)   # disparities up to 192: 1e-4 px
     np.testing.assert_allclose(sn, np.abs(x).sum(1), rtol=1e-5)
     want.backward(torch.from_numpy(go))
     gx = np.full_like(x, np.nan)
-    sim.call("ganet_norm_disparity_regression_backward", _p(x), _p(out), _p(sn), _p(go), _p(gx), N, D, H, W, None)
+    _call(sim, "ganet_norm_disparity_regression_backward", _p(x), _p(out), _p(sn), _p(go), _p(gx), N, D, H, W, None)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
@@ -86,11 +109,11 @@ def test_argument_errors(sim):
     from ganet_amd._native import GanetError
     a = np.zeros((1, 20, 2, 2), np.float32)
     with pytest.raises(GanetError, match="null"):
-        sim.call("ganet_l1_normalize_forward", None, _p(a), None, None, None, 1, 1, 1, 5, 2, 2, None)
+        _call(sim, "ganet_l1_normalize_forward", None, _p(a), None, None, None, 1, 1, 1, 5, 2, 2, None)
     with pytest.raises(GanetError, match="groups"):
-        sim.call("ganet_l1_normalize_forward", _p(a), _p(a), _p(a), _p(a), _p(a), 1, 5, 1, 5, 2, 2, None)
+        _call(sim, "ganet_l1_normalize_forward", _p(a), _p(a), _p(a), _p(a), _p(a), 1, 5, 1, 5, 2, 2, None)
     with pytest.raises(GanetError, match="null output 1"):
-        sim.call("ganet_l1_normalize_forward", _p(a), _p(a), None, None, None, 1, 2, 1, 5, 2, 2, None)
+        _call(sim, "ganet_l1_normalize_forward", _p(a), _p(a), None, None, None, 1, 2, 1, 5, 2, 2, None)
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 9, 4, 8), (2, 2, 5, 3, 5)])     # slice % 4 == 0 (16-byte path) and not
@@ -105,7 +128,7 @@ def test_sga_forward_infer_bn_relu_epilogue(sim, port_oracle, shape, with_bn):
     shift = rng.standard_normal(C).astype(np.float32)
     A = np.empty((4,) + shape, np.float32)
     out = np.full(shape, np.nan, np.float32)
-    sim.call("ganet_sga_forward_infer", _p(x), *[_p(g) for g in gs], _p(A), _p(out),
+    _call(sim, "ganet_sga_forward_infer", _p(x), *[_p(g) for g in gs], _p(A), _p(out),
              _p(scale) if with_bn else None, _p(shift) if with_bn else None, N, C, D, H, W, None)
     want, _, _ = port_oracle.sga_forward(x, *gs)
     if with_bn:
@@ -123,14 +146,14 @@ def test_softmin_forward_backward(sim, N, D, H, W):
     x[0, :, 0, 0] *= 20.0                                   # spread of ~100: the running-max rescale matters
     gy = rng.standard_normal((N, D, H, W)).astype(np.float32)
     y = np.full_like(x, np.nan)
-    sim.call("ganet_softmin_forward", _p(x), _p(y), N, D, H, W, None)
+    _call(sim, "ganet_softmin_forward", _p(x), _p(y), N, D, H, W, None)
     tx = torch.from_numpy(x).requires_grad_()
     want = torch.nn.functional.softmin(tx, dim=1)
     np.testing.assert_allclose(y, want.detach().numpy(), rtol=2e-6, atol=1e-7)
     want.backward(torch.from_numpy(gy))
     gx = np.full_like(x, np.nan)
     y_ref = np.ascontiguousarray(want.detach().numpy())          # (kept alive across the call)
-    sim.call("ganet_softmin_backward", _p(y_ref), _p(gy), _p(gx), N, D, H, W, None)
+    _call(sim, "ganet_softmin_backward", _p(y_ref), _p(gy), _p(gx), N, D, H, W, None)
     # (gy_d - sum gy*y cancels where y ~ 1: the order of the 193-term dot product shows up at the 1e-6 level)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-5, atol=1e-5)
 
@@ -144,13 +167,13 @@ def test_softmin_disparity_regression(sim, N, maxdisp, H, W):
     x[0, :, 0, 0] *= 15.0
     go = rng.standard_normal((N, H, W)).astype(np.float32)
     out, mx, ss = (np.full((N, H, W), np.nan, np.float32) for _ in range(3))
-    sim.call("ganet_softmin_regression_forward", _p(x), _p(out), _p(mx), _p(ss), N, D, H, W, None)
+    _call(sim, "ganet_softmin_regression_forward", _p(x), _p(out), _p(mx), _p(ss), N, D, H, W, None)
     tx = torch.from_numpy(x).requires_grad_()
     want = fr.disparity_regression(torch.nn.functional.softmin(tx, dim=1), maxdisp)
     np.testing.assert_allclose(out, want.detach().numpy(), rtol=1e-5, atol=1e-4)
     want.backward(torch.from_numpy(go))
     gx = np.full_like(x, np.nan)
-    sim.call("ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ss), _p(go), _p(gx), N, D, H, W, None)
+    _call(sim, "ganet_softmin_regression_backward", _p(x), _p(out), _p(mx), _p(ss), _p(go), _p(gx), N, D, H, W, None)
     np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
@@ -171,8 +194,8 @@ def test_trilinear_upsample_matches_torch(sim, isz, osz):
     yt.backward(torch.from_numpy(gy))
     y = np.full((1, S) + osz, np.nan, np.float32)
     gx = np.full_like(x, np.nan)
-    sim.call("ganet_trilinear_upsample_forward", x.ctypes.data, y.ctypes.data, S, *isz, *osz, None)
-    sim.call("ganet_trilinear_upsample_backward", gy.ctypes.data, gx.ctypes.data, S, *isz, *osz, None)
+    _call(sim, "ganet_trilinear_upsample_forward", _p(x), _p(y), S, *isz, *osz, None)
+    _call(sim, "ganet_trilinear_upsample_backward", _p(gy), _p(gx), S, *isz, *osz, None)
     np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
 
@@ -190,8 +213,8 @@ def test_lga_pass_with_regression_epilogue(sim, port_oracle, shape, r, with_y):
     y = np.full(shape, np.nan, np.float32)
     snorm = np.full((B, H, W), np.nan, np.float32)
     sdy = np.full((B, H, W), np.nan, np.float32)
-    sim.call("ganet_lga_forward_regress", x.ctypes.data, f.ctypes.data, y.ctypes.data if with_y else None, snorm.ctypes.data,
-             sdy.ctypes.data, B, D, H, W, r, None)
+    _call(sim, "ganet_lga_forward_regress", _p(x), _p(f), _p(y) if with_y else None, _p(snorm),
+             _p(sdy), B, D, H, W, r, None)
     if with_y:
         assert np.abs(y - want).max() < 2e-5
     d = np.arange(D, dtype=np.float64)[None, :, None, None]

@@ -76,24 +76,24 @@ def test_cost_volume_and_regression(sim, port_oracle, W):
     rng = np.random.default_rng(5)
     N, C, H, maxdisp = 2, 3, 4, 6
     Dn = maxdisp + 1
-    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
-    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
-    cost = np.empty((N, 2 * C, Dn, H, W), np.float32)
+    x = DEV.to(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    y = DEV.to(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    cost = DEV.empty((N, 2 * C, Dn, H, W))
     sim.call("ganet_cost_volume_forward", x.ctypes.data, y.ctypes.data, cost.ctypes.data, N, C, Dn, H, W, None)
     assert np.array_equal(cost, port_oracle.cost_volume(x, y, maxdisp))
     # adjoint identity <cost(x,y), g> == <x, gx> + <y, gy>
-    g = rng.standard_normal(cost.shape).astype(np.float32)
-    gx, gy = np.empty_like(x), np.empty_like(y)
+    g = DEV.to(rng.standard_normal(cost.shape).astype(np.float32))
+    gx, gy = DEV.empty(x.shape), DEV.empty(y.shape)
     sim.call("ganet_cost_volume_backward", g.ctypes.data, gx.ctypes.data, gy.ctypes.data, N, C, Dn, H, W, None)
     lhs = float((cost.astype(np.float64) * g).sum())
     rhs = float((x.astype(np.float64) * gx).sum() + (y.astype(np.float64) * gy).sum())
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
-    p = rng.random((N, Dn, H, W)).astype(np.float32)
-    out = np.empty((N, H, W), np.float32)
+    p = DEV.to(rng.random((N, Dn, H, W)).astype(np.float32))
+    out = DEV.empty((N, H, W))
     sim.call("ganet_disparity_regression_forward", p.ctypes.data, out.ctypes.data, N, Dn, H, W, None)
     np.testing.assert_allclose(out, port_oracle.disparity_regression(p, maxdisp), atol=1e-5)
-    go = rng.standard_normal((N, H, W)).astype(np.float32)
-    gp = np.empty_like(p)
+    go = DEV.to(rng.standard_normal((N, H, W)).astype(np.float32))
+    gp = DEV.empty(p.shape)
     sim.call("ganet_disparity_regression_backward", go.ctypes.data, gp.ctypes.data, N, Dn, H, W, None)
     want = go[:, None] * np.arange(Dn, dtype=np.float32)[None, :, None, None]
     assert np.array_equal(gp, want)
