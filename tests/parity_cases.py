@@ -27,10 +27,11 @@ _libc = ctypes.CDLL(None, use_errno=True)
 _libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 
 
-def guarded_empty(shape, dtype=np.float32):
+def guarded_empty(shape, dtype=np.float32, guard="end"):
     """An array whose last byte is followed by an inaccessible page (and whose mapping is preceded by one): a kernel that
     reads or writes past the end of a tensor -- harmless on the GPU as long as the neighbouring memory happens to be mapped,
-    a memory access fault once it is not (the 528x960 volumes of round 2) -- dies right here on the emulator."""
+    a memory access fault once it is not (the 528x960 volumes of round 2) -- dies right here on the emulator.
+    guard="start": the array BEGINS right behind the leading inaccessible page instead (accesses in front of a tensor)."""
     dtype = np.dtype(dtype)
     count = int(np.prod(shape, dtype=np.int64))
     nbytes = count * dtype.itemsize
@@ -40,7 +41,7 @@ def guarded_empty(shape, dtype=np.float32):
     for off in (0, _PAGE + body):
         if _libc.mprotect(base + off, _PAGE, 0) != 0:
             raise OSError(ctypes.get_errno(), "mprotect")
-    start = (_PAGE + body - nbytes) & ~15               # 16-byte aligned like any device allocation
+    start = _PAGE if guard == "start" else (_PAGE + body - nbytes) & ~15     # 16-byte aligned like any device allocation
     return np.frombuffer(mm, dtype, count, start).reshape(shape)
 
 
@@ -48,19 +49,22 @@ class NumpyDev:
     """Host buffers for the emulator build (every buffer ends at a guard page, see guarded_empty)."""
     stream = None
 
+    def __init__(self, guard="end"):
+        self.guard = guard
+
     def to(self, a):
         a = np.asarray(a)
-        g = guarded_empty(a.shape, a.dtype)
+        g = guarded_empty(a.shape, a.dtype, self.guard)
         g[...] = a
         return g
 
     def empty(self, shape, dtype=np.float32):
-        a = guarded_empty(shape, dtype)
+        a = guarded_empty(shape, dtype, self.guard)
         a.fill(np.nan if dtype == np.float32 else 113)     # poison: unwritten elements get noticed
         return a
 
     def zeros(self, shape, dtype=np.float32):
-        a = guarded_empty(shape, dtype)
+        a = guarded_empty(shape, dtype, self.guard)
         a.fill(0)
         return a
 

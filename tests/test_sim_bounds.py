@@ -1,0 +1,77 @@
+"""Bounds sweeps on the CPU emulator: every buffer ends at (or begins behind) an inaccessible page
+(parity_cases.guarded_empty), so an access outside a tensor is a crash, whatever the values read would have been used for.
+
+Why: the plane-pair LGA kernels of round 2 requested one plane past the end of the volume in their last steady step -- the
+data was never used, every parity test passed, and the GPU faulted only once a plane spanned whole pages and the tensor
+happened to be the last one of a mapped range (528x960, inside a training step).  The depth sweeps below walk every phase of
+the march against its ring / look-ahead / steady-body boundaries; the results are compared with the oracle as well."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from sim_util import sim_api
+    return sim_api()
+
+
+@pytest.mark.parametrize("guard", ["end", "start"])
+@pytest.mark.parametrize("wave,fg,segs", [(3, 3, 0), (3, 2, 0), (3, 3, 2), (2, 3, 0), (1, 3, 0)])
+def test_lga_depth_sweep_guarded(sim, port_oracle, wave, fg, segs, guard):
+    dev = pc.NumpyDev(guard)
+    sim.set_option("GANET_LGA_WAVE", wave)
+    sim.set_option("GANET_LGA_FG_WPS", fg)
+    sim.set_option("GANET_LGA_SEGS", segs)
+    try:
+        for D in range(1, 28):
+            for B, H, W in ((1, 3, 36),) + (((2, 2, 7),) if D % 4 == 1 else ()):
+                rng = np.random.default_rng(100 * D + W)
+                x = rng.standard_normal((B, D, H, W)).astype(np.float32)
+                f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+                gy = rng.standard_normal((B, D, H, W)).astype(np.float32)
+                y = port_oracle.lga_forward(x, f, 2)
+                gx, gf = port_oracle.lga_backward(x, f, gy, 2)
+                err = pc.check_lga_chain(sim, dev, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
+                assert max(err.values()) < 2e-5, (D, B, H, W, err)
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 3)
+        sim.set_option("GANET_LGA_FG_WPS", 3)
+        sim.set_option("GANET_LGA_SEGS", 0)
+
+
+@pytest.mark.parametrize("guard", ["end", "start"])
+@pytest.mark.parametrize("r", [1, 3])
+def test_lga_other_radii_guarded(sim, port_oracle, r, guard):
+    dev = pc.NumpyDev(guard)
+    for D in (1, 2, 9, 12, 13):
+        rng = np.random.default_rng(D + r)
+        shape = (1, D, 4, 34)
+        x = rng.standard_normal(shape).astype(np.float32)
+        f = pc.l1norm(rng.standard_normal((1, 3 * (2 * r + 1) ** 2, 4, 34)), 1)
+        gy = rng.standard_normal(shape).astype(np.float32)
+        y = port_oracle.lga_forward(x, f, r)
+        gx, gf = port_oracle.lga_backward(x, f, gy, r)
+        err = pc.check_lga_chain(sim, dev, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
+        assert max(err.values()) < 2e-5, (D, err)
+
+
+def _sga_want(oracle, x, gs, go):
+    out, tmp, mask = oracle.sga_forward(x, *gs)
+    grads = oracle.sga_backward(x, *gs, tmp, mask, go)
+    want = {"out": out, "mask": mask.astype(np.uint8), "tmp": tmp, "gx": grads[0]}
+    for d in range(4):
+        want[f"gw{d}"] = grads[1 + d]
+    return want
+
+
+# column-block kernels (W % 4 == 0, any H), row kernels (W % 4 == 0), strided fallbacks (odd W), D across the lane-group
+# sizes (<= 16 DPL 1, 17..80 DPL <= 5, > 80), single rows / columns
+@pytest.mark.parametrize("guard", ["end", "start"])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1, 4), (1, 2, 3, 2, 8), (1, 1, 16, 5, 16), (2, 1, 17, 3, 20), (1, 1, 33, 7, 12),
+                                   (1, 2, 65, 2, 36), (1, 1, 81, 3, 8), (1, 1, 5, 4, 7), (1, 1, 9, 1, 33), (1, 1, 7, 33, 1),
+                                   (1, 3, 4, 17, 32), (1, 1, 48, 9, 48)])
+def test_sga_shapes_guarded(sim, port_oracle, shape, guard):
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    pc.check_sga_forward_backward(sim, pc.NumpyDev(guard), x, gs, go, _sga_want(port_oracle, x, gs, go))

@@ -25,6 +25,18 @@ class _p:
         self.a = a
 
 
+_GUARD = "end"
+
+
+@pytest.fixture(autouse=True, params=["end", "start"])
+def guard_mode(request):
+    """Every test of this file runs twice: buffers that END at an inaccessible page, buffers that BEGIN behind one."""
+    global _GUARD
+    _GUARD = request.param
+    yield
+    _GUARD = "end"
+
+
 def _call(sim, name, *args):
     """sim.call with every array argument passed as a copy that ends at a guard page (parity_cases.guarded_empty): reads or
     writes past the end of a tensor crash here instead of depending on what the neighbouring memory is."""
@@ -32,7 +44,7 @@ def _call(sim, name, *args):
     bufs, conv = [], []
     for v in args:
         if isinstance(v, _p):
-            g = pc.guarded_empty(v.a.shape, v.a.dtype)
+            g = pc.guarded_empty(v.a.shape, v.a.dtype, _GUARD)
             g[...] = v.a
             bufs.append((v.a, g))
             conv.append(g.ctypes.data)

@@ -67,7 +67,7 @@ def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave
         err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 3)
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
@@ -125,7 +125,7 @@ def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split, wave):
         pc.check_lga_chain(sim, pc.NumpyDev(), x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
     finally:
         sim.set_option("GANET_LGA_SPLIT", 1)
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 3)
 
 
 @pytest.mark.parametrize("wps", [2, 3])
@@ -148,7 +148,7 @@ def test_plane_pair_filter_gradient_variants(sim, port_oracle, shape, r, wps):
         err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 2, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 3)
         sim.set_option("GANET_LGA_FG_WPS", 3)
 
 
@@ -170,6 +170,6 @@ def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs, split):
         err = pc.check_lga_chain(sim, DEV, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 3)
         sim.set_option("GANET_LGA_SEGS", 0)
         sim.set_option("GANET_LGA_SPLIT", 1)
