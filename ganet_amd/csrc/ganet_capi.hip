@@ -724,6 +724,9 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_POINT_BLOCK")) g_opt.point_block = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
+#if defined(GA_HIPSIM)
+  else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
+#endif
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
   return GANET_OK;
 }

@@ -615,7 +615,7 @@ template <int R> struct LgaDCfg {
 GA_DEV void lga_dma16(const float *gsrc, float *slot, int lane)
 {
 #if defined(GA_HIPSIM)
-  for (int k = 0; k < 4; k++) slot[4 * lane + k] = gsrc[k];
+  hipsim::dma_issue(slot + 4 * lane, gsrc, 4);
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
@@ -624,12 +624,16 @@ GA_DEV void lga_dma16(const float *gsrc, float *slot, int lane)
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 #endif
 }
+// GA_DMA_MASKED(n): this lane sits out n copy instructions its wave issues (the wave's counter counts them all the same);
+// nothing on the GPU, book-keeping for the emulator's late-landing copy model (tests/hipsim/hipsim.h)
 #if defined(GA_HIPSIM)
-#define GA_VMCNT(n) ((void)0)
+#define GA_VMCNT(n) hipsim::vmcnt(n)
 #define GA_LGKMCNT0() ((void)0)
+#define GA_DMA_MASKED(n) hipsim::dma_masked(n)
 #else
 #define GA_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define GA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define GA_DMA_MASKED(n) ((void)0)
 #endif
 
 template <int R, bool TRANSPOSED>
@@ -688,6 +692,7 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
   int dma_slot = 0;
   auto dma = [&](int k) {
     if (dma_on) lga_dma16(gsrc, ring + dma_slot * DC::PLANE, lane);
+    else GA_DMA_MASKED(1);
     gsrc += k + 1 < nvis ? geo.HW : 0;
     dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
   };
@@ -795,6 +800,7 @@ lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *_
 #else
           if (inb) *yp = r;
 #endif
+          GA_DMA_MASKED(1);                                   // (emulator: the y store is one more operation the relaxed wait counts)
           yp += geo.HW;
         }
         acc_a = live ? acc_b + z0 : acc_a;
@@ -852,7 +858,7 @@ template <int R> struct LgaPCfg {
 GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
 {
 #if defined(GA_HIPSIM)
-  slot[lane] = gsrc[0];
+  hipsim::dma_issue(slot + lane, gsrc, 1);
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
@@ -912,7 +918,8 @@ template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&
 {
 #if defined(GA_HIPSIM)
   for (int k = 0; k < ND; k++)
-    slot[k * 64 + lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + (LGAP_IMM_OFFSET ? 256 * k : 0));
+    hipsim::dma_issue(slot + k * 64 + lane,
+                      reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + (LGAP_IMM_OFFSET ? 256 * k : 0)), 1);
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
@@ -1042,6 +1049,7 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
         GA_WAVE_SYNC();
       }
       if ((lane & 1) == 0) lga_dma4p_all<ND>(gbase, goff, slot, lane);
+      else GA_DMA_MASKED(ND);
     } else {
       lga_dma4p_all<ND>(gbase, goff, slot, lane);
     }
@@ -1251,7 +1259,7 @@ lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__
 GA_DEV void lga_dma4s(const float *base, unsigned off, float *slot, int lane)
 {
 #if defined(GA_HIPSIM)
-  slot[lane] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off);
+  hipsim::dma_issue(slot + lane, reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off), 1);
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
@@ -1349,6 +1357,7 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
         GA_WAVE_SYNC();
       }
       if ((lane & 1) == 0) lga_dma4p_all<ND>(xsrc, goff, slot, lane);
+      else GA_DMA_MASKED(ND);
     } else {
       lga_dma4p_all<ND>(xsrc, goff, slot, lane);
     }
@@ -1548,7 +1557,7 @@ lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, fl
 GA_DEV void lga_dma4(const float *gsrc, float *slot, int lane)
 {
 #if defined(GA_HIPSIM)
-  slot[lane] = gsrc[0];
+  hipsim::dma_issue(slot + lane, gsrc, 1);
 #else
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
@@ -1624,6 +1633,7 @@ lga_filter_grad_dma(const float *__restrict__ x, const float *__restrict__ gy, f
   // x plane k (repeats the last plane past the end so that the operation count per step stays fixed)
   auto dma_x = [&](int k) {
     if (dma_on) lga_dma16(gsrc, ring + dma_slot * DC::PLANE, lane);
+    else GA_DMA_MASKED(1);
     gsrc += k + 1 < D ? geo.HW : 0;
     dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
   };

@@ -22,6 +22,7 @@
 #include <ucontext.h>
 
 #include <functional>
+#include <deque>
 #include <vector>
 
 #define __global__
@@ -78,6 +79,16 @@ struct State {
   std::vector<int> xchg;
   std::function<void()> body;
   char *dyn_smem = nullptr;
+  // global -> LDS copies (global_load_lds_*) in flight, per lane, oldest first.  late_dma == false: a copy lands when it is
+  // issued.  late_dma == true: it lands as LATE as the kernel's own s_waitcnt vmcnt(n) allows -- when the lane executes a
+  // wait that leaves at most n copies outstanding -- so a hand-counted wait that is one too loose reads a stale ring slot
+  // here, deterministically.  Only the copies are counted: the other vector-memory operations of a wave (tap gathers, result
+  // stores) are younger or older than the copies around them and can only make the real wait more conservative than this
+  // model (vmcnt retires in issue order on gfx9), never less.
+  struct DmaOp { float *dst; float v[4]; int n; };
+  std::vector<std::deque<DmaOp>> dma;
+  bool late_dma = false;
+  long dma_late_landed = 0;
 };
 
 inline State &S() { static State s; return s; }
@@ -94,6 +105,28 @@ inline void barrier_wait(Barrier &b, int n)
 inline int flat_tid() { State &s = S(); const dim3 &t = s.fibers[s.cur].tidx; return t.x + s.blockDim_.x * (t.y + s.blockDim_.y * t.z); }
 inline int lane_id() { return flat_tid() & 63; }
 inline void syncthreads() { State &s = S(); barrier_wait(s.block_bar, s.nthreads); }
+
+inline void dma_land(const State::DmaOp &op) { for (int k = 0; k < op.n; k++) op.dst[k] = op.v[k]; }
+// one lane's share of a global -> LDS copy instruction: n floats from src to dst (n == 0: the lane is masked out of the
+// instruction, which the wave's counter counts all the same)
+inline void dma_issue(float *dst, const float *src, int n)
+{
+  State &s = S();
+  State::DmaOp op;
+  op.dst = dst; op.n = n;
+  for (int k = 0; k < n; k++) op.v[k] = src[k];
+  if (!s.late_dma) { dma_land(op); return; }
+  s.dma[flat_tid()].push_back(op);
+}
+inline void dma_masked(int count) { for (int i = 0; i < count; i++) dma_issue(nullptr, nullptr, 0); }
+// s_waitcnt vmcnt(n)
+inline void vmcnt(int n)
+{
+  State &s = S();
+  if (!s.late_dma) return;
+  auto &q = s.dma[flat_tid()];
+  while ((int)q.size() > n) { dma_land(q.front()); q.pop_front(); s.dma_late_landed++; }
+}
 
 inline int update_dpp(int old, int src, int ctrl)
 {
@@ -135,6 +168,11 @@ inline void fiber_entry()
 {
   State &s = S();
   s.body();
+  if (s.late_dma && !s.dma[flat_tid()].empty()) {
+    fprintf(stderr, "hipsim: thread %d ended with %d global->LDS copies in flight (its LDS may already belong to the next workgroup)\n",
+            flat_tid(), (int)s.dma[flat_tid()].size());
+    abort();
+  }
   s.fibers[s.cur].done = true;
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
@@ -155,6 +193,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
   }
   s.wave_bar.assign((nt + 63) / 64, Barrier());
   s.xchg.assign(nt, 0);
+  s.dma.assign(nt, std::deque<State::DmaOp>());
   std::vector<char> smem(shmem + 64);
   s.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
   for (unsigned bz = 0; bz < grid.z; bz++)

@@ -75,3 +75,37 @@ def _sga_want(oracle, x, gs, go):
 def test_sga_shapes_guarded(sim, port_oracle, shape, guard):
     x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
     pc.check_sga_forward_backward(sim, pc.NumpyDev(guard), x, gs, go, _sga_want(port_oracle, x, gs, go))
+
+
+# ---- hand-counted s_waitcnt vmcnt(n) under the emulator's LATE-LANDING copy model --------------------------------------
+# (tests/hipsim/hipsim.h: a global -> LDS copy lands only when a wait of its lane leaves no room for it any more, i.e. as late
+# as the kernel's own waits permit; a thread that ends with copies in flight aborts).  A count that is one too loose, a wait
+# placed behind the first read of a slot, or a missing final wait gives wrong results / an abort HERE instead of a
+# timing-dependent stale read on the GPU ("the emulator compiles GA_VMCNT to a no-op").
+@pytest.mark.parametrize("wave,fg,safe,segs", [(3, 3, 0, 0), (3, 2, 0, 0), (3, 3, 0, 2), (3, 3, 0, 3), (2, 3, 0, 0), (2, 3, 1, 0),
+                                               (2, 3, 0, 2)])
+def test_lga_counted_waits_with_late_landing_copies(sim, port_oracle, wave, fg, safe, segs):
+    dev = pc.NumpyDev()
+    sim.set_option("GANET_LGA_WAVE", wave)
+    sim.set_option("GANET_LGA_FG_WPS", fg)
+    sim.set_option("GANET_LGA_VMCNT_SAFE", safe)
+    sim.set_option("GANET_LGA_SEGS", segs)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        for shape in [(1, D, 3, 36) for D in (1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 19, 20, 21, 26, 27, 40, 41)] + \
+                     [(2, 13, 5, 68), (1, 22, 2, 8), (1, 15, 9, 40), (1, 33, 1, 4)]:
+            rng = np.random.default_rng(sum(shape))
+            B, D, H, W = shape
+            x = rng.standard_normal(shape).astype(np.float32)
+            f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+            gy = rng.standard_normal(shape).astype(np.float32)
+            y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+            gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+            err = pc.check_lga_chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+            assert max(err.values()) < 2e-5, (shape, err)
+    finally:
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+        sim.set_option("GANET_LGA_WAVE", 3)
+        sim.set_option("GANET_LGA_FG_WPS", 3)
+        sim.set_option("GANET_LGA_VMCNT_SAFE", 0)
+        sim.set_option("GANET_LGA_SEGS", 0)
