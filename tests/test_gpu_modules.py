@@ -232,3 +232,67 @@ def test_loss_functions_on_gpu_match_cpu(torch_mod):
     a2, b2 = a.detach().clone().requires_grad_(), b.clone().requires_grad_()
     MyLoss()(a2, b2).backward()
     assert b2.grad is not None and float(b2.grad.abs().max()) == 0.0
+
+
+def test_concurrent_python_threads_on_one_device(torch_mod, port_oracle):
+    """SURVEY 8b, threading: under nn.DataParallel (the reference's train.py:73) one Python thread per replica calls the
+    ops concurrently and autograd's engine threads call the backwards.  Here: four threads on ONE device, each on its own
+    stream with its own inputs, several rounds of SGA + LGA2 forward / backward; every result must equal the oracle's
+    (forward bit-exact) -- no shared scratch, no shared error state, options read-only."""
+    import threading
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.modules.GANet import SGA, LGA2
+    nthreads, rounds = 4, 3
+    cases = []
+    for t in range(nthreads):
+        g = torch.Generator(device="cpu").manual_seed(100 + t)
+        x = torch.randn(1, 2, 17 + 8 * t, 9, 24, generator=g)
+        gs = [F.normalize(torch.randn(1, 2, 5, 9, 24, generator=g), p=1, dim=2) for _ in range(4)]
+        go = torch.randn(x.shape, generator=g)
+        lx = torch.randn(1, 11 + 2 * t, 7, 36, generator=g)
+        lf = F.normalize(torch.randn(1, 75, 7, 36, generator=g), p=1, dim=1)
+        lgy = torch.randn(lx.shape, generator=g)
+        cases.append((x, gs, go, lx, lf, lgy))
+    results, errors = [None] * nthreads, []
+    start = threading.Barrier(nthreads)
+
+    def work(t):
+        try:
+            x, gs, go, lx, lf, lgy = cases[t]
+            stream = torch.cuda.Stream()
+            out = []
+            start.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(rounds):
+                    dx = x.cuda().requires_grad_()
+                    dgs = [g.cuda().requires_grad_() for g in gs]
+                    o = SGA()(dx, *dgs)
+                    o.backward(go.cuda())
+                    dl = lx.cuda().requires_grad_()
+                    df = lf.cuda().requires_grad_()
+                    y = LGA2(radius=2)(dl, df)
+                    y.backward(lgy.cuda())
+                    stream.synchronize()
+                    out.append((_np(o), [_np(v.grad) for v in [dx] + dgs], _np(y), _np(dl.grad), _np(df.grad)))
+            results[t] = out
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(nthreads):
+        x, gs, go, lx, lf, lgy = cases[t]
+        o_out, o_tmp, o_mask = port_oracle.sga_forward(x.numpy(), *[g.numpy() for g in gs])
+        o_g = port_oracle.sga_backward(x.numpy(), *[g.numpy() for g in gs], o_tmp, o_mask, go.numpy())
+        o_y, ins = port_oracle.lga_chain_forward(lx.numpy(), lf.numpy(), 2, 2)
+        o_gx, o_gf = port_oracle.lga_chain_backward(ins, lf.numpy(), lgy.numpy(), 2)
+        for out, grads, y, gx, gf in results[t]:
+            assert np.array_equal(out, o_out), t
+            for got, want in zip(grads, o_g):
+                assert np.abs(got - want).max() <= pc.TOL, t
+            assert np.abs(y - o_y).max() <= pc.TOL and np.abs(gx - o_gx).max() <= pc.TOL and np.abs(gf - o_gf).max() <= pc.TOL, t
