@@ -7,7 +7,8 @@ libganet_hip.so; (hyb) the GPU model with ONLY the GA ops swapped for the oracle
   gpu vs hyb isolates this library: the rest of the model is the same MIOpen / ATen-HIP arithmetic on both sides.  Bars:
       disparities within 1e-2 absolute in eval and 2e-2 in training mode (range 0..48; observed 2e-3 / 5.5e-3),
       gradients cosine >= 0.9999 and median per-tensor rel-L2 <= 2e-2 (observed: GANet11 2.5e-3 / 0.999997, GANet_deep with
-      its seven SGA layers 7.3e-3 / 0.99997; the test also prints the gpu-vs-gpu noise floor).  Not tighter: the ops agree with
+      its seven SGA layers 7.3e-3 / 0.99997), both widened to 4x / 3x the gpu-vs-gpu noise floor of the same run when that
+      is larger (profiles/r2w_model_and_threads.txt: the same arm twice gave 1 - cosine = 2.9e-4, gpu vs hyb 3.0e-4).  Not tighter: the ops agree with
       the oracle to 2e-7 (LGA) / bit-exactly (SGA forward), but a randomly initialised GANet amplifies that through
       F.normalize(p=1) of a signed LGA output and 48-level regression; MIOpen's weight-gradient kernels use atomics, so
       even gpu vs gpu is not bit-reproducible; and the SGA direction choice / arg-max routing is discontinuous -- a few
@@ -101,7 +102,11 @@ def test_reference_model_on_gpu_matches_cpu_oracle_twin(env, port_oracle, name):
               f"grad rel-L2 median {med:.3e} worst {worst[1]:.3e} ({worst[0]})  cosine {cos:.8f}")
         assert e_eval <= bars["e_eval"] and e_train <= bars["e_train"], (other, e_eval, e_train)
         assert abs(res["gpu"][1] - res[other][1]) <= 1e-3 * abs(res[other][1])
-        assert med <= bars["med"] and cos >= bars["cos"], (other, med, cos)
+        # the gradient bars move with the noise floor measured above: on some boxes two runs of the SAME gpu arm already differ
+        # by 1 - cosine = 3e-4 (GANet_deep; 3e-5 on others), and the comparison with another arm cannot be better than that
+        med_bar = max(bars["med"], 3 * n_med)
+        cos_bar = min(bars["cos"], 1 - 4 * (1 - n_cos))
+        assert med <= med_bar and cos >= cos_bar, (other, med, cos, med_bar, cos_bar)
 
 
 def test_fused_call_sites_equal_stock_call_forms(env):
