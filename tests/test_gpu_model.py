@@ -6,7 +6,7 @@ Three arms: (cpu) everything on the CPU, GA ops through the oracle; (gpu) the pr
 libganet_hip.so; (hyb) the GPU model with ONLY the GA ops swapped for the oracle (host round trip per op).
   gpu vs hyb isolates this library: the rest of the model is the same MIOpen / ATen-HIP arithmetic on both sides.  Bars:
       disparities within 1e-2 absolute in eval and 2e-2 in training mode (range 0..48; observed 2e-3 / 5.5e-3),
-      gradients cosine >= 0.9999 and median per-tensor rel-L2 <= 2e-2 (observed: GANet11 2.5e-3 / 0.999997, GANet_deep with
+      gradients cosine >= 0.9995 and median per-tensor rel-L2 <= 2e-2 (observed: GANet11 2.5e-3 / 0.999997, GANet_deep with
       its seven SGA layers 7.3e-3 / 0.99997), both widened to 4x / 3x the gpu-vs-gpu noise floor of the same run when that
       is larger (profiles/r2w_model_and_threads.txt: the same arm twice gave 1 - cosine = 2.9e-4, gpu vs hyb 3.0e-4).  Not tighter: the ops agree with
       the oracle to 2e-7 (LGA) / bit-exactly (SGA forward), but a randomly initialised GANet amplifies that through
@@ -14,7 +14,9 @@ libganet_hip.so; (hyb) the GPU model with ONLY the GA ops swapped for the oracle
       even gpu vs gpu is not bit-reproducible; and the SGA direction choice / arg-max routing is discontinuous -- a few
       pixels pick another branch after 1e-7 upstream differences.
   gpu vs cpu additionally carries PyTorch's own CPU-vs-MIOpen differences through ~60 layers, which nobody controls to
-      1e-4: disparities within 2e-3 of the disparity range, median per-tensor gradient rel-L2 <= 3e-2, cosine >= 0.999."""
+      1e-4: disparities within 2e-3 of the disparity range, median per-tensor gradient rel-L2 <= 3e-2, cosine >= 0.998
+      (observed 0.99957 .. 0.99999).  These are sanity bars on a chaotic system (a broken op gives cosine << 0.99); the
+      guarantees are the per-op parity tests."""
 import os
 import subprocess
 import sys
@@ -93,8 +95,8 @@ def test_reference_model_on_gpu_matches_cpu_oracle_twin(env, port_oracle, name):
     again = {k: p.grad.detach().cpu() for k, p in gpu.named_parameters() if p.grad is not None}
     n_med, n_worst, n_cos = _grad_cmp(torch, again, res["gpu"][2])
     print(f"{name} gpu vs gpu (same arm twice): grad rel-L2 median {n_med:.3e} worst {n_worst[1]:.3e}  1-cosine {1 - n_cos:.3e}")
-    for other, bars in (("hyb", dict(e_eval=1e-2, e_train=2e-2, med=2e-2, cos=0.9999)),
-                        ("cpu", dict(e_eval=2e-3 * max_disp, e_train=2e-3 * max_disp, med=3e-2, cos=0.999))):
+    for other, bars in (("hyb", dict(e_eval=1e-2, e_train=2e-2, med=2e-2, cos=0.9995)),
+                        ("cpu", dict(e_eval=2e-3 * max_disp, e_train=2e-3 * max_disp, med=3e-2, cos=0.998))):
         e_eval = float((d["gpu"] - d[other]).abs().max())
         e_train = max(float((a - b).abs().max()) for a, b in zip(res["gpu"][0], res[other][0]))
         med, worst, cos = _grad_cmp(torch, res[other][2], res["gpu"][2])
