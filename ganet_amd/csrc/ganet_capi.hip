@@ -726,6 +726,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
+  else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;
 #endif
   else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
   return GANET_OK;

@@ -89,6 +89,10 @@ struct State {
   std::vector<std::deque<DmaOp>> dma;
   bool late_dma = false;
   long dma_late_landed = 0;
+  // order in which the runnable threads of a block are resumed between two barriers: 0 = ascending thread index,
+  // 1 = descending.  A hand-off through LDS that lacks a barrier is decided by whichever thread runs first; results that
+  // are the same in both orders do not depend on that luck.
+  int lane_order = 0;
 };
 
 inline State &S() { static State s; return s; }
@@ -215,7 +219,8 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
         int remaining = nt;
         long spins = 0;
         while (remaining > 0) {
-          for (int t = 0; t < nt; t++) {
+          for (int i = 0; i < nt; i++) {
+            const int t = s.lane_order ? nt - 1 - i : i;
             if (s.fibers[t].done) continue;
             s.cur = t;
             swapcontext(&s.sched, &s.fibers[t].ctx);

@@ -109,3 +109,46 @@ def test_lga_counted_waits_with_late_landing_copies(sim, port_oracle, wave, fg, 
         sim.set_option("GANET_LGA_FG_WPS", 3)
         sim.set_option("GANET_LGA_VMCNT_SAFE", 0)
         sim.set_option("GANET_LGA_SEGS", 0)
+
+
+# ---- thread scheduling order of the emulator ----------------------------------------------------------------------------
+# Between two barriers the emulator runs the threads of a block one after the other; a hand-off through LDS that lacks a
+# barrier (or a wave barrier where a workgroup barrier is needed) is then decided by the order.  Everything below also
+# runs with the threads resumed in DESCENDING order (and the copies landing late): same results required.
+@pytest.fixture()
+def reversed_lanes(sim):
+    sim.set_option("HIPSIM_LANE_ORDER", 1)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    yield
+    sim.set_option("HIPSIM_LANE_ORDER", 0)
+    sim.set_option("HIPSIM_LATE_DMA", 0)
+
+
+@pytest.mark.parametrize("wave,fg,segs", [(3, 3, 0), (3, 2, 2), (2, 3, 0), (1, 3, 2), (0, 3, 0)])
+def test_lga_families_with_reversed_thread_order(sim, port_oracle, reversed_lanes, wave, fg, segs):
+    dev = pc.NumpyDev()
+    sim.set_option("GANET_LGA_WAVE", wave)
+    sim.set_option("GANET_LGA_FG_WPS", fg)
+    sim.set_option("GANET_LGA_SEGS", segs)
+    try:
+        for shape in [(1, 1, 3, 36), (1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 26, 2, 7), (1, 14, 9, 34)]:
+            rng = np.random.default_rng(sum(shape))
+            B, D, H, W = shape
+            x = rng.standard_normal(shape).astype(np.float32)
+            f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+            gy = rng.standard_normal(shape).astype(np.float32)
+            y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+            gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+            err = pc.check_lga_chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+            assert max(err.values()) < 2e-5, (shape, err)
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 3)
+        sim.set_option("GANET_LGA_FG_WPS", 3)
+        sim.set_option("GANET_LGA_SEGS", 0)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 3, 2, 8), (1, 1, 16, 5, 16), (2, 1, 17, 3, 20), (1, 2, 65, 2, 36), (1, 1, 81, 3, 8),
+                                   (1, 1, 5, 4, 7), (1, 3, 4, 17, 32), (1, 1, 48, 9, 48), (1, 1, 300, 3, 8)])
+def test_sga_with_reversed_thread_order(sim, port_oracle, reversed_lanes, shape):
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    pc.check_sga_forward_backward(sim, pc.NumpyDev(), x, gs, go, _sga_want(port_oracle, x, gs, go))
