@@ -71,8 +71,10 @@ def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
+@pytest.mark.parametrize("guard", ["end", "start"])
 @pytest.mark.parametrize("W", [11, 12, 8])      # scalar kernels (W % 4 != 0) and the four-columns-per-lane ones
-def test_cost_volume_and_regression(sim, port_oracle, W):
+def test_cost_volume_and_regression(sim, port_oracle, W, guard):
+    DEV = pc.NumpyDev(guard)
     rng = np.random.default_rng(5)
     N, C, H, maxdisp = 2, 3, 4, 6
     Dn = maxdisp + 1
