@@ -11,6 +11,7 @@
   hipsim::launch((grid), (block), 0, [=]() { kern(__VA_ARGS__); })
 #define GA_LAUNCH_SMEM(kern, grid, block, smem, stream, ...) \
   hipsim::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define GA_LAUNCH_SMEM_BIG GA_LAUNCH_SMEM
 #define GA_EXPORT extern "C"
 #else
 // hipGetLastError() is per-thread state shared with the host framework.  An error some earlier, unrelated HIP call left
@@ -31,6 +32,14 @@ inline void ga_note_stale_error()
   do { ga_note_stale_error(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
 #define GA_LAUNCH(kern, grid, block, stream, ...) \
   do { ga_note_stale_error(); hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__); } while (0)
+// more than 64 KB of dynamic LDS (gfx950 has 160 KB per CU): the limit of the kernel has to be raised first
+#define GA_LAUNCH_SMEM_BIG(kern, grid, block, smem, stream, ...)                                                         \
+  do {                                                                                                                   \
+    ga_note_stale_error();                                                                                               \
+    if ((smem) > 64 * 1024)                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)); \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                                            \
+  } while (0)
 #define GA_EXPORT extern "C" __attribute__((visibility("default")))
 #endif
 

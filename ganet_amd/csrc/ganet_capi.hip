@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
   std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> wide_col{0};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks); 0 = off (not measured yet)
   std::atomic<int> wide_scan{1};    // SGA scans with the whole wavefront on one scanline: 1 for inputs with few scanlines (and D > 272), 0 never, 2 whenever D > 48 (tests)
   std::atomic<int> lga_bwd_streams{0};   // 1: filter gradient and data-backward of an LGA backward pass on two streams
   std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
@@ -97,6 +98,7 @@ void load_env_options()
   geti("GANET_LGA_FG_WPS", g_opt.lga_fg_wps);
   geti("GANET_LGA_BWD_STREAMS", g_opt.lga_bwd_streams);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
+  geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
   geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
@@ -314,6 +316,62 @@ int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
   return check_launch("sga column-block forward");
 }
 
+// ---- the same column blocks with one WAVEFRONT per column (sga_col_fwd_wide / sga_col_bwdg_wide; GANET_SGA_WIDE_COL) -----
+// For inputs with few column blocks (SURVEY 8d's stress shape [1,1,192,240,624]: 39 blocks) and many disparities: 16 waves
+// per block instead of 4, 3-5 disparities of serial work per lane instead of 12-13, and -- unlike the register-only wide
+// segment kernels -- the same 64-byte global pieces as the 16-lane column blocks.  D <= 192; up to 112 KB of LDS per block.
+constexpr size_t COL_WIDE_SMEM_MAX = 152 * 1024;
+int col_wide_dpl(int D) { return D <= 64 * 3 ? 3 : 0; }      // (5 disparities per lane spill at the 128 registers a 1,024-thread block leaves)
+bool col_wide_ok(int D, int W, int dir, size_t smem, int S)
+{
+  return opts().wide_col && dir < 2 && W % 4 == 0 && col_wide_dpl(D) > 0 && smem <= COL_WIDE_SMEM_MAX && S <= 65535;
+}
+
+int col_fwd_wide(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  ColGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0;
+  const int dpl = col_wide_dpl(D);
+  const bool full = D % dpl == 0;
+  const size_t smem = col_smem_fwd(D);
+  const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(1024);
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 0 && full) GA_LAUNCH_SMEM_BIG((sga_col_fwd_wide<P, true, true>), grid, block, smem, st, x, g, A, geo);   \
+    else if (dir == 0) GA_LAUNCH_SMEM_BIG((sga_col_fwd_wide<P, true, false>), grid, block, smem, st, x, g, A, geo);     \
+    else if (full) GA_LAUNCH_SMEM_BIG((sga_col_fwd_wide<P, false, true>), grid, block, smem, st, x, g, A, geo);         \
+    else GA_LAUNCH_SMEM_BIG((sga_col_fwd_wide<P, false, false>), grid, block, smem, st, x, g, A, geo);                  \
+  }
+  X(3)
+#undef X
+  static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;
+  if (trace) fprintf(stderr, "[ganet] sga_col_fwd_wide DPL=%d dir=%d D=%d smem=%zu\n", dpl, dir, D, smem);
+  return check_launch("sga wide column-block forward");
+}
+
+int col_bwdg_wide(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
+                  int S, int D, int H, int W, int dir, hipStream_t st)
+{
+  ColGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0;
+  const int dpl = col_wide_dpl(D);
+  const size_t smem = col_smem_bwdg(D);
+  const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(1024);
+  const bool m16 = W % 16 == 0 && aligned16(mask);
+#define X(P)                                                                                        \
+  if (dpl == (P)) {                                                                                 \
+    if (dir == 1 && m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
+    else if (dir == 1) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);   \
+    else if (m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);        \
+    else GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);                \
+  }
+  X(3)
+#undef X
+  static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;
+  if (trace) fprintf(stderr, "[ganet] sga_col_bwdg_wide DPL=%d dir=%d D=%d smem=%zu\n", dpl, dir, D, smem);
+  return check_launch("sga wide column-block adjoint scan");
+}
+
 int col_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
              int S, int D, int H, int W, int dir, hipStream_t st)
 {
@@ -377,6 +435,8 @@ bool few_lines(int N, int C, int D, int H, int W, int dir)
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
              hipStream_t st)
 {
+  if (col_wide_ok(D, W, dir, col_smem_fwd(D), N * C) && aligned16(x) && aligned16(g) && aligned16(A))
+    return col_fwd_wide(x, g, A, N * C, D, H, W, dir, st);
   if (few_lines(N, C, D, H, W, dir)) {
     int gd, dpl;
     if (pick_pair(D, 64, &gd, &dpl)) {
@@ -403,6 +463,9 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
 int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
               int N, int C, int D, int H, int W, int dir, hipStream_t st)
 {
+  if (col_wide_ok(D, W, dir, col_smem_bwdg(D), N * C) && aligned16(g) && aligned16(gout) && aligned16(G) &&
+      (((uintptr_t)mask & 3) == 0))
+    return col_bwdg_wide(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   if (few_lines(N, C, D, H, W, dir)) {
     int gd, dpl;
     if (pick_pair(D, 64, &gd, &dpl)) {
@@ -715,6 +778,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_FG_WPS")) g_opt.lga_fg_wps = value == 2 ? 2 : 3;
   else if (!strcmp(name, "GANET_LGA_BWD_STREAMS")) g_opt.lga_bwd_streams = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;

@@ -230,6 +230,9 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
  *   GANET_SGA_WIDE_SCAN=0|1|2  scans with the whole wavefront on one scanline: never | for inputs with few scanlines and for
  *                         D > 272 (default) | whenever D > 48
+ *   GANET_SGA_WIDE_COL=0|1  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
+ *                         D <= 192; for inputs with few column blocks).  Default 0: checked on the CPU emulator, not yet
+ *                         measured on a GPU (scripts/check_wide_col.py)
  *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans (segment kernels)
  *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: segment kernels)
  *   GANET_SGA_MERGE4 = 0|1  four-pixels-per-lane merge + arg-max (default 1)

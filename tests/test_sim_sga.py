@@ -85,6 +85,27 @@ def test_horizontal_kernel_families(sim, port_oracle, shape, rowwave):
         sim.set_option("GANET_SGA_ROWWAVE", 1)
 
 
+@pytest.mark.parametrize("mode", ["plain", "guard_start", "late_reversed"])
+@pytest.mark.parametrize("shape", [(1, 1, 192, 5, 16), (1, 2, 65, 7, 20), (2, 1, 7, 9, 8), (1, 1, 100, 6, 36), (1, 1, 150, 3, 12),
+                                   (1, 1, 3, 1, 4), (1, 1, 191, 2, 40)])
+def test_vertical_wide_column_blocks(sim, port_oracle, shape, mode):
+    """GANET_SGA_WIDE_COL=1: the LDS-staged column blocks with one wavefront per column (1,024-thread blocks, 3 disparities per
+    lane, D <= 192): down / up forward and adjoint scans bit-exact / within tolerance of the oracle, incl. partial column
+    blocks, H not a multiple of the 4-row batch, D not a multiple of 3; also with buffers behind a guard page and with the
+    emulator's reversed thread order."""
+    sim.set_option("GANET_SGA_WIDE_COL", 1)
+    if mode == "late_reversed":
+        sim.set_option("HIPSIM_LANE_ORDER", 1)
+    try:
+        x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+        dev = pc.NumpyDev("start" if mode == "guard_start" else "end")
+        err = pc.check_sga_forward_backward(sim, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+        assert max(err.values()) < 3e-5, err
+    finally:
+        sim.set_option("GANET_SGA_WIDE_COL", 0)
+        sim.set_option("HIPSIM_LANE_ORDER", 0)
+
+
 @pytest.mark.parametrize("colblock", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 2, 6, 3, 4), (2, 1, 20, 9, 20), (1, 1, 65, 5, 36), (1, 1, 130, 2, 8), (1, 2, 33, 13, 48)])
 def test_vertical_kernel_families(sim, port_oracle, shape, colblock):
