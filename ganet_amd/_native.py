@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -33,6 +33,7 @@ _PROTOS = {
     "ganet_lga_forward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_lga_backward": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_lga_forward_regress": [_P] * 5 + [_I] * 5 + [_P],
+    "ganet_lga_apply_paired": [_P] * 3 + [_I] * 8 + [_P],
     "ganet_cost_volume_forward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_disparity_regression_forward": [_P] * 2 + [_I] * 4 + [_P],

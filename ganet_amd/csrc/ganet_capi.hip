@@ -652,6 +652,30 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   return check_launch("lga apply");
 }
 
+// one LGA pass / data-backward with one side in the pair-interleaved layout (lga_apply_pp_pi / lga_apply_pp_po)
+int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, bool transposed, bool x_paired,
+                      hipStream_t st)
+{
+  if ((i64)H * W >= (1ll << 28) || W % 2 != 0 || !aligned16(x) || !aligned16(y))
+    return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: needs W even, planes below 2^28 pixels and 16-byte aligned volumes");
+  LgaGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  LgaSeg sg;
+  sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+  sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+  sg.nseg = 1; sg.seg_len = (D + 1) & ~1; sg.split_a = 0; sg.safe_wait = 0;
+  const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+  if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: too many tiles");
+  if (x_paired) {
+    if (transposed) GA_LAUNCH((lga_apply_pp_pi<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    else GA_LAUNCH((lga_apply_pp_pi<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+  } else {
+    if (transposed) GA_LAUNCH((lga_apply_pp_po<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    else GA_LAUNCH((lga_apply_pp_po<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+  }
+  return check_launch("lga apply (plane pairs, interleaved volume)");
+}
+
 // one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
 template <int R>
 int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D, int H, int W,
@@ -1012,6 +1036,17 @@ GA_EXPORT int ganet_lga_forward(const float *x, const float *f, float *y, int B,
   if (radius == 1) return launch_lga_fwd<1>(x, f, y, B, D, H, W, false, st);
   if (radius == 2) return launch_lga_fwd<2>(x, f, y, B, D, H, W, false, st);
   return launch_lga_fwd<3>(x, f, y, B, D, H, W, false, st);
+}
+
+GA_EXPORT int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, int radius,
+                                     int transposed, int x_paired, int y_paired, void *stream)
+{
+  if (!x || !f || !y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: null pointer");
+  if (x == y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: y must not alias x");
+  GA_TRY(check_lga("ganet_lga_apply_paired", B, D, H, W, radius));
+  if (!!x_paired == !!y_paired) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: exactly one of x_paired / y_paired");
+  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: radius 2 only");
+  return launch_lga_paired(x, f, y, B, D, H, W, transposed != 0, x_paired != 0, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,

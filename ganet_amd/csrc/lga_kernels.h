@@ -985,275 +985,70 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
   }
 }
 
-// EPI: the pass also reduces its own output over the disparity axis per pixel -- snorm = sum_d |y|, sdy = sum_d d * y, what
-// F.normalize(p=1, dim=1) + DisparityRegression at the end of DispAgg.forward (models/GANet_deep.py:246-247) need -- and y
-// itself is stored only if the pointer is given (inference does not need it).  One depth segment per tile in that mode.
-template <int R, bool TRANSPOSED, bool EPI = false>
-__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
-lga_apply_pp(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
-             LgaGeom geo, LgaSeg sg, float *__restrict__ snorm_out = nullptr, float *__restrict__ sdy_out = nullptr)
+// both 16-byte copies of one pair of a pair-interleaved volume (lga_apply_pp.inc, GA_PP_IN): copy k moves lane l's 16 bytes
+// from base + o[k] to slot + 1024 k + 16 l; one M0, the second copy through the immediate offset (see lga_dma4p_all)
+GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *slot, int lane)
 {
-  typedef LgaPCfg<R> PC;
-  constexpr int WS = PC::WS, K = WS * WS, NR = LGAP_NR, P = NR - 1, ND = PC::NDMA;
-  __shared__ __attribute__((aligned(16))) float ring[NR * PC::SLOT];
-  const int lane = threadIdx.x;                       // blockDim.x == 64
-  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int bx, by, b, d_lo, d_hi;
-  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);   // the launcher makes every segment start on an even plane
-  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
-  const int i = ty0 + ty, j = tx0 + tx;
-  const bool inb = i < geo.H && j < geo.W;
-  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
-  const float *xb = x + (i64)b * geo.D * geo.HW;
-  const float *fb = f + (i64)b * 3 * K * geo.HW;
-  float *yb = y + (i64)b * geo.D * geo.HW;
-  const i64 pix = (i64)ic * geo.W + jc;
-  if (d_lo >= geo.D) return;
-
-  // output planes [d_lo, d_hi) need input planes [d_lo - 1, min(d_hi, D - 1)]: pairs m_lo .. m_hi
-  const int D = geo.D;
-  const int p_hi = d_hi < D ? d_hi : D - 1;           // last input plane needed
-  const int m_lo = d_lo > 0 ? (d_lo - 1) >> 1 : 0;
-  const int m_hi = p_hi >> 1;
-  const int npair = m_hi - m_lo + 1;
-
-  // per-lane byte offset of every copy of a pair (clamped into the image), relative to the pair's even plane
-  unsigned goff[ND];
-#pragma unroll
-  for (int k = 0; k < ND; k++) {
-    const int e = k * 64 + lane;
-    int cell = e >> 1;
-    cell = cell < PC::CELLS ? cell : PC::CELLS - 1;   // (padding cells of the last copy: any valid address)
-    const int r = cell / PC::TW2, c = cell - r * PC::TW2;
-    int i2 = ty0 + r - R, j2 = tx0 + c - R;
-    i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
-    j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
-    goff[k] = lga_pp_off(4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2)), k);   // (launcher: 2 HW floats < 2^30)
-  }
-  // uniform: even plane of the next pair to request, LGAP_BIAS bytes low (see lga_dma4p_all)
-  const float *gbase = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb + (i64)(2 * m_lo) * geo.HW) - LGAP_BIAS);
-  // pairs are requested in order q = 0, 1, 2, ... (relative to m_lo); past the last one the last is requested again so that
-  // the operation count per step stays fixed.  half: the pair's odd plane does not exist (2 m + 1 == D).
-  int dma_slot = 0;
-  auto dma = [&](int q) {
-    const int qq = q < npair ? q : npair - 1;
-    const bool half = 2 * (m_lo + qq) + 1 >= D;       // uniform
-    float *slot = ring + dma_slot * PC::SLOT;
-    if (half) {
-      if (q < npair) {                                // the one real half pair: its odd cells must read as zero
-        if (lane & 1) {
-#pragma unroll
-          for (int k = 0; k < ND; k++) slot[k * 64 + lane] = 0.f;
-        }
-        GA_LGKMCNT0();
-        GA_WAVE_SYNC();
-      }
-      if ((lane & 1) == 0) lga_dma4p_all<ND>(gbase, goff, slot, lane);
-      else GA_DMA_MASKED(ND);
-    } else {
-      lga_dma4p_all<ND>(gbase, goff, slot, lane);
-    }
-    if (q + 1 < npair) gbase += 2 * geo.HW;
-    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-  };
-  for (int q = 0; q < P; q++) dma(q);
-
-  // weights: tap t = (dd * WS + a) * WS + b lives in half (t & 1) of register pair t >> 1
-  constexpr int NT = 3 * K, NWP = (NT + 1) / 2;
-  f2 wq[NWP];
-  float cmid = 0.f, sin_m = 0.f, sin_p = 0.f;
-  const bool interior = ty0 >= R && ty0 + LGAW_TH + R <= geo.H && tx0 >= R && tx0 + LGA_TW + R <= geo.W;
-  if (interior)
-    lga_gather_pairs<R, TRANSPOSED, false>(fb, geo, ic, jc, wq, cmid, sin_m, sin_p);
-  else
-    lga_gather_pairs<R, TRANSPOSED, true>(fb, geo, ic, jc, wq, cmid, sin_m, sin_p);
-
-  // window rows stream through a register ring with LA rows of LDS look-ahead (rows of the NEXT pair for the last LA rows)
-  // (the epilogue variant carries two more running sums and the plane index as a float: one row less of look-ahead keeps
-  // it spill-free -- a spill inside the march would break the hand-counted vmcnt, scripts/isa_loop_check.py)
-  constexpr int LA = EPI ? 1 : LGAW_LA;
-  static_assert(WS > LA, "look-ahead must stay within the next pair");
-  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + 2 * (ty * PC::TW2 + tx);
-  f2 vrow[LA + 1][WS];
-  GA_VMCNT(0);                                             // everything requested so far has landed (pair 0 is what is needed;
-  GA_WAVE_SYNC();                                          // a counted wait here would be fooled by a prologue spill)
-#pragma unroll
-  for (int s0 = 0; s0 < LA; s0++) {
-#pragma unroll
-    for (int bb = 0; bb < WS; bb++) vrow[s0][bb] = lds_read_b64(lbase + 2 * (s0 * PC::TW2 + bb));
-  }
-
-  f2 o_prev = mk2(0.f, 0.f);                     // O_{m-1} so far: (y[2m-1], y[2m]) contributions of pair m-1
-  float e_hi_prev = 0.f;                         // E_{m-1}.hi
-  float xc_prev = 0.f;                           // centre sample of plane 2m-1
-  // ring positions as running float offsets (no multiplications in the march)
-  int soff_c = 0;                                // slot of the pair being computed
-  int soff_d = (P % NR) * PC::SLOT;              // slot the next copy batch goes to (== dma_slot * SLOT)
-  // the row ring has LA + 1 entries and a pair has WS rows: unroll U pairs so that the ring closes (U * WS % (LA + 1) == 0)
-  constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
-  constexpr int NSTEP = U * WS;
-  static_assert(NSTEP % (LA + 1) == 0, "row ring must close");
-
-  // One group = U pair-steps.  What limits these kernels is the NUMBER of instructions a wave has to issue per plane, of
-  // any kind (profiles/r1p_pmc_summary.txt: scalar bookkeeping took as much wave time as the FMAs; cutting 20 % of the VALU
-  // alone changed nothing, profiles/r2d_ab_lga_plane_pairs_v1.txt), so the march has two bodies: STEADY -- every step is a
-  // full pair with both outputs inside the segment, plain centre coefficient and a full pair to request: no predicates, no
-  // index arithmetic beyond three ring offsets and the output pointer -- and the general
-  // one for the first and last groups of a segment.
-  float *yp = yb + pix;                                        // (re-seated when the steady groups begin)
-  const bool store_y = !EPI || y != nullptr;                   // uniform
-  float e_abs = 0.f, e_dy = 0.f;                               // EPI: sum_d |y[d]|, sum_d d * y[d] of the own pixel
-  auto group = [&](auto steady_tag, int q0) {
-    constexpr bool STEADY = decltype(steady_tag)::value;
-    f2 eA, eB, pA, pB, cA, cB;                   // E_m, O_{m-1} increment, O_m: two chains each
-    f2 xc2 = mk2(0.f, 0.f);
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-      const int u = st / WS, a = st % WS;
-      const int q = q0 + u;
-      const int m = m_lo + q;
-      if (a == 0) {                              // overwrites the slot of pair q - 1, whose rows have all been consumed
-        if (STEADY) {
-#if !(LGAP_ABLATE & 1)
-          lga_dma4p_all<ND>(gbase, goff, ring + soff_d, lane);
-#endif
-          gbase += 2 * geo.HW;
-          dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-        } else {
-          dma(q + P);
-        }
-        soff_d = soff_d + PC::SLOT == NR * PC::SLOT ? 0 : soff_d + PC::SLOT;
-      }
-      const int soff_n = soff_c + PC::SLOT == NR * PC::SLOT ? 0 : soff_c + PC::SLOT;
-      const lds_cptr cur = lbase + soff_c, nxt = lbase + soff_n;
-      if (a == WS - LA) {
-        // pair q + 1 must have landed.  After its copies came those of P - 1 further pairs (and y stores, which only make
-        // this wait earlier than necessary: counting them -- vmcnt((ND + 2)(P - 1)) -- was measured and bought nothing,
-        // profiles/r2e_ab_lga_plane_pairs_v2.txt, so the count that needs no assumption about the stores is the only one)
-#if !(LGAP_ABLATE & 3)
-        GA_VMCNT(ND * (P - 1));
-#endif
-        GA_WAVE_SYNC();
-      }
-      {
-        const int t = a + LA;
-        const lds_cptr src = t < WS ? cur + 2 * t * PC::TW2 : nxt + 2 * (t - WS) * PC::TW2;
-#pragma unroll
-        for (int bb = 0; bb < WS; bb++) {
-#if LGAP_ABLATE & 4
-          if (STEADY) GA_KEEP_F2(vrow[(st + LA) % (LA + 1)][bb]);
-          else
-#endif
-          vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
-        }
-      }
-      GA_SCHED_FENCE();
-      // taps of the row from the LAST one read to the first: the wait for the last covers the whole row (LDS returns in
-      // order), so a row costs one s_waitcnt instead of one per tap
-#pragma unroll
-      for (int b2 = 0; b2 < WS; b2++) {
-        const int bb = WS - 1 - b2;
-        const f2 X = vrow[st % (LA + 1)][bb];
-        const int tm = (0 * WS + a) * WS + bb, t0 = (1 * WS + a) * WS + bb, tp = (2 * WS + a) * WS + bb;   // slabs -1, 0, +1
-        const int n = a * WS + b2;                        // taps alternate between two chains per accumulator
-#define GA_PP_ACC(acc, t)                                                                                    \
-        acc = n < 2 ? ((t & 1) ? mul2_bcast<1>(X, wq[t >> 1]) : mul2_bcast<0>(X, wq[t >> 1]))               \
-                    : ((t & 1) ? fma2_bcast<1>(X, wq[t >> 1], acc) : fma2_bcast<0>(X, wq[t >> 1], acc))
-#if LGAP_ABLATE & 8
-        if (STEADY && n >= 2) { GA_KEEP_F2(eA); } else
-#endif
-        if (n & 1) { GA_PP_ACC(eB, t0); GA_PP_ACC(pB, tp); GA_PP_ACC(cB, tm); }
-        else { GA_PP_ACC(eA, t0); GA_PP_ACC(pA, tp); GA_PP_ACC(cA, tm); }
-#undef GA_PP_ACC
-        GA_SCHED_FENCE();
-        if (a == R && bb == R) xc2 = X;
-      }
-      if (a == WS - 1) {
-        GA_KEEP_F2(eA); GA_KEEP_F2(eB); GA_KEEP_F2(pA); GA_KEEP_F2(pB); GA_KEEP_F2(cA); GA_KEEP_F2(cB);
-        const f2 e = add2(eA, eB);
-        const f2 o = add2(o_prev, add2(pA, pB));           // O_{m-1} complete
-        if (STEADY) {
-          const float r1 = fmaf(xc_prev, cmid, e_hi_prev + o.x);      // y[2m-1]
-          const float r2 = fmaf(xc2.x, cmid, e.x + o.y);              // y[2m]
-#if LGAP_ABLATE & 2
-          if (inb && r1 == 123.456f) yp[0] = r1 + r2;
-          yp += 2 * geo.HW;
+  static_assert(LGAP_IMM_OFFSET == 1, "written for the immediate-offset form");
+#if defined(GA_HIPSIM)
+  for (int k = 0; k < 2; k++)
+    hipsim::dma_issue(slot + k * 256 + 4 * lane, reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + 1024 * k), 4);
 #else
-          if (inb && store_y) yp[0] = r1;
-          yp += geo.HW;
-          if (inb && store_y) yp[0] = r2;
-          yp += geo.HW;
+  (void)lane;
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %3, %2 offset:0\n\tglobal_load_lds_dwordx4 %4, %2 offset:1024\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]) : "memory", "scc");
 #endif
-          if (EPI) {
-            e_abs += fabsf(r1) + fabsf(r2);
-            e_dy = fmaf((float)(2 * m - 1), r1, fmaf((float)(2 * m), r2, e_dy));
-          }
-          o_prev = add2(cA, cB);
-          e_hi_prev = e.y;
-          xc_prev = xc2.y;
-        } else {
-          const bool live = q < npair;                       // uniform
-          const int d1 = 2 * m - 1, d2 = 2 * m;
-          if (live && d1 >= d_lo && d1 < d_hi) {
-            float cc = cmid;
-            if (d1 == D - 1) cc += sin_p;                    // (d1 is odd: never plane 0)
-            const float r = fmaf(xc_prev, cc, e_hi_prev + o.x);
-            if (inb && store_y) yb[(i64)d1 * geo.HW + pix] = r;
-            if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d1, r, e_dy); }
-          }
-          if (live && d2 >= d_lo && d2 < d_hi) {
-            float cc = cmid;
-            if (d2 == 0) cc += sin_m;
-            if (d2 == D - 1) cc += sin_p;
-            const float r = fmaf(xc2.x, cc, e.x + o.y);
-            if (inb && store_y) yb[(i64)d2 * geo.HW + pix] = r;
-            if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d2, r, e_dy); }
-          }
-          if (live) {
-            o_prev = add2(cA, cB);
-            e_hi_prev = e.y;
-            xc_prev = xc2.y;
-          }
-        }
-        soff_c = soff_n;
-      }
-    }
-  };
-  // steady steps q in [ql, qh): q + P a full pair inside the segment's request range; both outputs inside
-  // [max(d_lo, 1), min(d_hi, D - 1))
-  const int ql = ((d_lo + 2) >> 1) - m_lo;
-  // (q + P + 1 < npair: the steady body advances the request pointer unconditionally, so the pair AFTER the one it requests
-  // must exist too -- with q + P == npair - 1 the pointer would end one pair past the volume and the re-requests of the
-  // general body would read there: a fault at the end of the last batch element once a plane pair spans whole pages)
-  int qh = npair - P - 1;
-  if ((D >> 1) - m_lo - P < qh) qh = (D >> 1) - m_lo - P;
-  {
-    const int L = d_hi < D - 1 ? d_hi : D - 1;
-    if (((L - 2 * m_lo + 1) >> 1) < qh) qh = (L - 2 * m_lo + 1) >> 1;
-  }
-  int q0 = 0;
-  for (; q0 < npair && q0 < ql; q0 += U) group(std::false_type{}, q0);
-  if (q0 + U <= qh) yp = yb + (i64)(2 * (m_lo + q0) - 1) * geo.HW + pix;
-  for (; q0 + U <= qh; q0 += U) group(std::true_type{}, q0);
-  for (; q0 < npair; q0 += U) group(std::false_type{}, q0);
-  {
-    // even D at the end of the volume: plane D - 1 = 2 m_hi + 1 has no later pair to be completed by
-    const int d1 = 2 * m_hi + 1;
-    if (d1 >= d_lo && d1 < d_hi && d1 < D) {
-      float cc = cmid;
-      if (d1 == D - 1) cc += sin_p;
-      const float r = fmaf(xc_prev, cc, e_hi_prev + o_prev.x);
-      if (inb && store_y) yb[(i64)d1 * geo.HW + pix] = r;
-      if (EPI) { e_abs += fabsf(r); e_dy = fmaf((float)d1, r, e_dy); }
-    }
-  }
-  if (EPI && inb) {
-    const i64 op = (i64)b * geo.HW + pix;
-    snorm_out[op] = e_abs;
-    sdy_out[op] = e_dy;
-  }
-  GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
 }
+
+// ---- lga_apply_pp (API layout in, API layout out) and its pair-interleaved forms: lga_apply_pp.inc --------------------------
+#define GA_PP_NAME lga_apply_pp
+#define GA_PP_IN 0
+#define GA_PP_OUT 0
+#define GA_PP_SLOT PC::SLOT
+#define GA_PP_NDC ND
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+
+#define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
+// API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
+#define GA_PP_NAME lga_apply_pp_po
+#define GA_PP_IN 0
+#define GA_PP_OUT 1
+#define GA_PP_SLOT PC::SLOT
+#define GA_PP_NDC ND
+#define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+// pair-interleaved in, API layout out (second pass of an LGA2; data-backward of its first pass)
+#define GA_PP_NAME lga_apply_pp_pi
+#define GA_PP_IN 1
+#define GA_PP_OUT 0
+#define GA_PP_SLOT 512
+#define GA_PP_NDC 2
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+#undef GA_PP_Y_PAIRED
 
 // one 4-byte global -> LDS copy per lane, scalar base + 32-bit lane offset: lane l's dword lands at slot + 4 * l
 GA_DEV void lga_dma4s(const float *base, unsigned off, float *slot, int lane)

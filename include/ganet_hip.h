@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 6
+#define GANET_ABI_VERSION 7
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -138,6 +138,17 @@ int ganet_lga_forward(const float *x, const float *f, float *y,
  * does not apply (radius 3, planes of 2^28 pixels or more): run the two separate entries instead. */
 int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy,
                               int B, int D, int H, int W, int radius, void *stream);
+
+/* ABI v7.  One LGA pass (transposed = 0: as ganet_lga_forward) or its data-backward (transposed = 1: x is the output gradient,
+ * y the input gradient, as the second half of ganet_lga_backward) on volumes in the PAIR-INTERLEAVED layout
+ * [B][ceil(D/2)][H][W][2] -- planes 2m and 2m+1 of a pixel adjacent; for odd D the odd half of the last pair is zero (written
+ * so by this entry when y is interleaved; required of x when x is interleaved).  x_paired / y_paired select the layout of
+ * either side; exactly one of them must be set.  The layout is for volumes that never cross the operator API: the
+ * intermediate between the two passes of an LGA2 (functions/GANet.py:176-187) and its gradient -- a consumer stages a plane
+ * pair with two 16-byte copies per lane instead of seven 4-byte ones, a producer stores a pair with one 8-byte store.
+ * radius 2 only, W even, 16-byte aligned volumes; GANET_E_UNSUPPORTED otherwise (use the API-layout entries). */
+int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, int radius,
+                           int transposed, int x_paired, int y_paired, void *stream);
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,

@@ -198,3 +198,21 @@ def check_lga_chain(api, dev, x, f, gy, r, passes, want):
            "gf": float(np.abs(dev.host(gf) - want["gf"]).max())}
     assert max(err.values()) <= TOL, err
     return err
+
+
+def to_paired(v):
+    """[B, D, H, W] -> the pair-interleaved layout [B, ceil(D/2), H, W, 2] of ganet_lga_apply_paired (odd D: zero odd half)."""
+    B, D, H, W = v.shape
+    out = np.zeros((B, (D + 1) // 2, H, W, 2), np.float32)
+    out[..., 0] = v[:, 0::2]
+    out[:, :D // 2, :, :, 1] = v[:, 1::2]
+    return out
+
+
+def from_paired(p, D):
+    B, _, H, W, _ = p.shape
+    v = np.empty((B, D, H, W), np.float32)
+    v[:, 0::2] = p[..., 0][:, :(D + 1) // 2]
+    v[:, 1::2] = p[..., 1][:, :D // 2]
+    return v
+

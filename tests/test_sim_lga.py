@@ -175,3 +175,46 @@ def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs, split):
         sim.set_option("GANET_LGA_WAVE", 3)
         sim.set_option("GANET_LGA_SEGS", 0)
         sim.set_option("GANET_LGA_SPLIT", 1)
+
+
+@pytest.mark.parametrize("mode", ["guard_end", "guard_start", "late_reversed"])
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 1, 3, 34), (1, 2, 2, 2), (1, 26, 2, 6),
+                                   (1, 40, 3, 32), (1, 41, 7, 64), (1, 14, 9, 34)])
+def test_apply_on_pair_interleaved_volumes(sim, port_oracle, shape, mode):
+    """ganet_lga_apply_paired (ABI v7): one pass and its data-backward with the input OR the output volume in the
+    pair-interleaved layout (the private intermediate of an LGA2): equal to the oracle on the API layout, zero padding of the
+    last pair for odd D, depths on both sides of the steady body, border tiles, widths that are not a multiple of the tile."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    dev = pc.NumpyDev("start" if mode == "guard_start" else "end")
+    if mode == "late_reversed":
+        sim.set_option("HIPSIM_LATE_DMA", 1)
+        sim.set_option("HIPSIM_LANE_ORDER", 1)
+    try:
+        df = dev.to(f)
+        for tr in (0, 1):
+            want = port_oracle.lga_forward(x, f, 2) if tr == 0 else port_oracle.lga_backward(np.zeros_like(x), f, x, 2)[0]
+            xp, y = dev.to(pc.to_paired(x)), dev.empty(shape)
+            sim.call("ganet_lga_apply_paired", dev.ptr(xp), dev.ptr(df), dev.ptr(y), B, D, H, W, 2, tr, 1, 0, None)
+            assert np.abs(y - want).max() < 2e-5, ("paired in", tr)
+            dx, yp = dev.to(x), dev.empty((B, (D + 1) // 2, H, W, 2))
+            sim.call("ganet_lga_apply_paired", dev.ptr(dx), dev.ptr(df), dev.ptr(yp), B, D, H, W, 2, tr, 0, 1, None)
+            assert np.abs(pc.from_paired(yp, D) - want).max() < 2e-5, ("paired out", tr)
+            assert D % 2 == 0 or (yp[:, -1, :, :, 1] == 0).all(), "odd half of the last pair must be zero"
+    finally:
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+        sim.set_option("HIPSIM_LANE_ORDER", 0)
+
+
+def test_apply_paired_argument_errors(sim):
+    from ganet_amd._native import GanetError
+    x = DEV.zeros((1, 4, 2, 4))
+    with pytest.raises(GanetError, match="exactly one"):
+        sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 4))), 1, 4, 2, 4, 2, 0, 1, 1, None)
+    with pytest.raises(GanetError, match="radius 2"):
+        sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 4))), 1, 4, 2, 4, 1, 0, 1, 0, None)
+    with pytest.raises(GanetError, match="W even"):
+        sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 3))), 1, 4, 2, 3, 2, 0, 1, 0, None)
+
