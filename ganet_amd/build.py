@@ -13,7 +13,7 @@ SOURCES = {
     # few per cent faster with it
     "sga_row_fwd_tu.hip": ["-fno-slp-vectorize"],
 }
-HEADERS = ["ga_common.h", "ga_launch.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "sga_col_kernels.inc", "lga_kernels.h", "lga_apply_pp.inc",
+HEADERS = ["ga_common.h", "ga_launch.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "sga_col_kernels.inc", "lga_kernels.h", "lga_apply_pp.inc", "lga_filter_grad_pp.inc",
            "misc_kernels.h"]
 LIB_SONAME = "libganet_hip.so"
 OUT = os.path.join(_HERE, LIB_SONAME)

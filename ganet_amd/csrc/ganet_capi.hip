@@ -676,6 +676,23 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   return check_launch("lga apply (plane pairs, interleaved volume)");
 }
 
+int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc, hipStream_t st)
+{
+  if ((i64)H * W >= (1ll << 28) || W % 2 != 0 || !aligned16(x))
+    return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: needs W even, planes below 2^28 pixels and a 16-byte aligned x");
+  LgaGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  LgaSeg sg;
+  sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+  sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+  sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
+  const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+  if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
+  if (opts().lga_fg_wps == 2) GA_LAUNCH((lga_filter_grad_pp_xp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  else GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  return check_launch("lga filter grad (plane pairs, interleaved x)");
+}
+
 // one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
 template <int R>
 int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D, int H, int W,
@@ -1044,9 +1061,19 @@ GA_EXPORT int ganet_lga_apply_paired(const float *x, const float *f, float *y, i
   if (!x || !f || !y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: null pointer");
   if (x == y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: y must not alias x");
   GA_TRY(check_lga("ganet_lga_apply_paired", B, D, H, W, radius));
-  if (!!x_paired == !!y_paired) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: exactly one of x_paired / y_paired");
+  if (x_paired && y_paired) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: at most one of x_paired / y_paired");
   if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: radius 2 only");
+  if (!x_paired && !y_paired) return launch_lga_fwd<2>(x, f, y, B, D, H, W, transposed != 0, (hipStream_t)stream);
   return launch_lga_paired(x, f, y, B, D, H, W, transposed != 0, x_paired != 0, (hipStream_t)stream);
+}
+
+GA_EXPORT int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
+                                           int accumulate_gf, void *stream)
+{
+  if (!x || !gy || !gf) return fail(GANET_E_INVALID, "ganet_lga_filter_grad_paired: null pointer");
+  GA_TRY(check_lga("ganet_lga_filter_grad_paired", B, D, H, W, radius));
+  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: radius 2 only");
+  return launch_lga_gf_paired(x, gy, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,

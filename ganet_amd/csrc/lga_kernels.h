@@ -1090,263 +1090,25 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
 // bookkeeping of the march is only valid while the compiler adds NO vector-memory operation of its own to the loop -- a
 // register spill is one (scratch_load / scratch_store count in vmcnt) -- so the (WPS, LA) pairs offered by the launcher are
 // the ones scripts/isa_lint.py finds spill-free inside the loop: (3, 0) and (2, 2) at R = 2.
-template <int R, int WPS, int LA_>
-__global__ void __launch_bounds__(64, WPS)
-lga_filter_grad_pp(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
-                   LgaGeom geo, LgaSeg sg, int accumulate)
-{
-  typedef LgaPCfg<R> PC;
-  constexpr int WS = PC::WS, K = WS * WS, NR = LGAP_NR, P = NR - 1, ND = PC::NDMA, NGS = 2 * P + 4, VPS = ND + 2;
-  static_assert(VPS * P < 64, "vmcnt immediate");
-  __shared__ __attribute__((aligned(16))) float ring[NR * PC::SLOT];
-  __shared__ __attribute__((aligned(16))) float gring[NGS * 64];
-  __shared__ unsigned goff_lds[ND * 64];               // per-lane byte offsets of the x copies, parked here between steps
-  const int lane = threadIdx.x;                       // blockDim.x == 64
-  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int item = xcd_remap(blockIdx.x, gridDim.x);        // tiles along a row first; each XCD a contiguous band
-  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
-  const int by = item % sg.tiles_y;
-  const int b = item / sg.tiles_y;
-  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
-  const int i = ty0 + ty, j = tx0 + tx;
-  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
-  const float *xb = x + (i64)b * geo.D * geo.HW;
-  const float *gyb = gy + (i64)b * geo.D * geo.HW;
-  const i64 pix = (i64)ic * geo.W + jc;
-  const int D = geo.D;
-  const int npair = (D + 1) >> 1;
-
-  unsigned goff[ND];
-#pragma unroll
-  for (int k = 0; k < ND; k++) {
-    const int e = k * 64 + lane;
-    int cell = e >> 1;
-    cell = cell < PC::CELLS ? cell : PC::CELLS - 1;
-    const int r = cell / PC::TW2, c = cell - r * PC::TW2;
-    int i2 = ty0 + r - R, j2 = tx0 + c - R;
-    i2 = i2 < 0 ? 0 : (i2 < geo.H ? i2 : geo.H - 1);
-    j2 = j2 < 0 ? 0 : (j2 < geo.W ? j2 : geo.W - 1);
-    goff[k] = lga_pp_off(4u * ((unsigned)(e & 1) * (unsigned)geo.HW + (unsigned)(i2 * geo.W + j2)), k);
-    goff_lds[k * 64 + lane] = goff[k];
-  }
-  const unsigned gyoff = 4u * (unsigned)pix;
-  // uniform: even plane of the next x pair to request, LGAP_BIAS bytes low (see lga_dma4p_all)
-  const float *xsrc = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xb) - LGAP_BIAS);
-  const float *gysrc = gyb;                            // uniform: next gy plane to request
-  int dma_slot = 0, g_slot = 0;
-  auto dma_x = [&](int q, bool reload) {               // x pair q (past the end: the last pair again, fixed operation count)
-    if (reload) {
-#pragma unroll
-      for (int k = 0; k < ND; k++) goff[k] = goff_lds[k * 64 + lane];
-    }
-    const int qq = q < npair ? q : npair - 1;
-    const bool half = 2 * qq + 1 >= D;                 // uniform
-    float *slot = ring + dma_slot * PC::SLOT;
-    if (half) {
-      if (q < npair) {
-        if (lane & 1) {
-#pragma unroll
-          for (int k = 0; k < ND; k++) slot[k * 64 + lane] = 0.f;
-        }
-        GA_LGKMCNT0();
-        GA_WAVE_SYNC();
-      }
-      if ((lane & 1) == 0) lga_dma4p_all<ND>(xsrc, goff, slot, lane);
-      else GA_DMA_MASKED(ND);
-    } else {
-      lga_dma4p_all<ND>(xsrc, goff, slot, lane);
-    }
-    if (q + 1 < npair) xsrc += 2 * geo.HW;
-    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-  };
-  auto dma_g = [&](int k) {                            // gy plane k (clamped; its value is masked where k >= D)
-    lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
-    if (k + 1 < D) gysrc += geo.HW;
-    g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
-  };
-  // gy ring: plane k lives in slot k % NGS
-  dma_g(0);
-  for (int q = 0; q < P; q++) { dma_g(2 * q + 1); dma_g(2 * q + 2); dma_x(q, false); }
-
-  f2 Pq[WS][WS], Qq[WS][WS];
-#pragma unroll
-  for (int a = 0; a < WS; a++) {
-#pragma unroll
-    for (int bb = 0; bb < WS; bb++) Pq[a][bb] = Qq[a][bb] = mk2(0.f, 0.f);
-  }
-  float gc = 0.f;                 // sum_d gy[d] * x[d][centre]
-  float e_lo = 0.f, e_hi = 0.f;   // gy[0]*x[0][c], gy[D-1]*x[D-1][c]
-
-  constexpr int LA = LA_;
-  static_assert(WS > LA, "look-ahead must stay within the next pair");
-  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + 2 * (ty * PC::TW2 + tx);
-  const lds_cptr gbase = GA_LDS_CPTR(&gring[0]) + lane;
-  f2 vrow[LA + 1][WS];
-  GA_VMCNT(0);                                             // everything requested so far has landed (pair 0 is what is needed;
-  GA_WAVE_SYNC();                                          // a counted wait here would be fooled by a prologue spill)
-#pragma unroll
-  for (int s0 = 0; s0 < LA; s0++) {
-#pragma unroll
-    for (int bb = 0; bb < WS; bb++) vrow[s0][bb] = lds_read_b64(lbase + 2 * (s0 * PC::TW2 + bb));
-  }
-  int soff_c = 0;                                // x ring: float offset of the slot of the pair being visited
-  int soff_d = (P % NR) * PC::SLOT;              //         ... of the slot the next copy batch goes to
-  int gs = 0;                                    // gy ring slot of plane 2q
-  constexpr int U = (WS % (LA + 1) == 0) ? 1 : (LA + 1);
-  constexpr int NSTEP = U * WS;
-  // two bodies as in lga_apply_pp: STEADY = a step whose requests (x pair q + P, gy planes 2(q+P)+1, +2) and multipliers
-  // (gy planes 2q-1 .. 2q+2) all exist and which touches neither end of the volume -- no predicates, no clamping
-  auto group = [&](auto steady_tag, int q0) {
-    constexpr bool STEADY = decltype(steady_tag)::value;
-    f2 Ga = mk2(0.f, 0.f), Gb = mk2(0.f, 0.f), Gc = mk2(0.f, 0.f);
-    f2 xc2 = mk2(0.f, 0.f);
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-      const int u = st / WS, a = st % WS;
-      const int q = q0 + u;
-      const bool live = STEADY || q < npair;               // uniform
-      if (a == 0) {
-        // the slots these overwrite held x pair q - 1 and gy planes 2q - 3, 2q - 2: all consumed (the lanes of a wave run in
-        // lockstep; the wave barrier is a compiler fence here and a real one in the CPU emulator)
-        GA_WAVE_SYNC();
-        if (STEADY) {
-          lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
-          gysrc += geo.HW;
-          g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
-          lga_dma4s(gysrc, gyoff, gring + g_slot * 64, lane);
-          gysrc += geo.HW;
-          g_slot = g_slot + 1 == NGS ? 0 : g_slot + 1;
-#pragma unroll
-          for (int k = 0; k < ND; k++) goff[k] = goff_lds[k * 64 + lane];
-          lga_dma4p_all<ND>(xsrc, goff, ring + soff_d, lane);
-          xsrc += 2 * geo.HW;
-          dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-        } else {
-          dma_g(2 * (q + P) + 1);
-          dma_g(2 * (q + P) + 2);
-          dma_x(q + P, true);
-        }
-        soff_d = soff_d + PC::SLOT == NR * PC::SLOT ? 0 : soff_d + PC::SLOT;
-      }
-      const int soff_n = soff_c + PC::SLOT == NR * PC::SLOT ? 0 : soff_c + PC::SLOT;
-      const lds_cptr cur = lbase + soff_c, nxt = lbase + soff_n;
-      if ((a + LA) % WS == 0) {
-        // the rows read from here on belong to x pair q + 1 (LA > 0) or q (LA = 0): it -- and with it gy up to two planes
-        // past it -- must have landed.  After its last copy came VPS operations for each later pair up to q + P.
-        GA_VMCNT(VPS * (P - (LA > 0 ? 1 : 0)));
-        GA_WAVE_SYNC();
-      }
-      if (a == 0) {
-        // gy[2q-1 .. 2q+2] of the own pixel (0 outside [0, D)); all landed: they precede x pair q in issue order
-        const int s_m1 = gs == 0 ? NGS - 1 : gs - 1, s_p1 = gs + 1 == NGS ? 0 : gs + 1, s_p2 = s_p1 + 1 == NGS ? 0 : s_p1 + 1;
-        const float gm1v = gbase[s_m1 * 64];
-        const float g0v = gbase[gs * 64];
-        const float g1v = gbase[s_p1 * 64], g2v = gbase[s_p2 * 64];
-        if (STEADY) {
-          Ga = mk2(g1v, g0v);
-          Gb = mk2(g2v, g1v);
-          Gc = mk2(gm1v, g0v);
-        } else {
-          const float gm1 = (q > 0 && live) ? gm1v : 0.f;
-          const float g1 = 2 * q + 1 < D ? g1v : 0.f;
-          const float g2 = 2 * q + 2 < D ? g2v : 0.f;
-          const float g0 = live ? g0v : 0.f;               // a step past the last pair runs on zero multipliers (no branch
-                                                           // around the FMAs: the 100 accumulators would meet at a merge)
-          Ga = mk2(g1, g0);
-          Gb = mk2(g2, g1);
-          Gc = mk2(gm1, g0);
-        }
-      }
-      {
-        const int t = a + LA;
-        const lds_cptr src = t < WS ? cur + 2 * t * PC::TW2 : nxt + 2 * (t - WS) * PC::TW2;
-#pragma unroll
-        for (int bb = 0; bb < WS; bb++) vrow[(st + LA) % (LA + 1)][bb] = lds_read_b64(src + 2 * bb);
-      }
-      GA_SCHED_FENCE();
-      // last tap read first: its wait covers the row (LDS returns in order)
-#pragma unroll
-      for (int b2 = 0; b2 < WS; b2++) {
-        const int bb = WS - 1 - b2;
-        const f2 X = vrow[st % (LA + 1)][bb];
-        Pq[a][bb] = fma2(mk2(X.x, X.x), Ga, Pq[a][bb]);     // (a splat of a freshly loaded value: the compiler's own op_sel)
-        Qq[a][bb] = fma2(X, Gc, Qq[a][bb]);
-        if (a == R && bb == R) xc2 = X;
-      }
-#pragma unroll
-      for (int b2 = 0; b2 < WS; b2++) {
-        const int bb = WS - 1 - b2;
-        const f2 X = vrow[st % (LA + 1)][bb];
-        Pq[a][bb] = fma2(mk2(X.y, X.y), Gb, Pq[a][bb]);
-      }
-      GA_SCHED_FENCE();
-      if (a == WS - 1) {
-        {
-          // Ga = (g[2q+1], g[2q]) (zeros past the end), centre samples xc2 = (x[2q][c], x[2q+1][c])
-          const float e0 = Ga.y * xc2.x, e1 = Ga.x * xc2.y;
-          gc += e0 + e1;
-          if (!STEADY) {
-            if (q == 0) e_lo = e0;
-            if (2 * q == D - 1) e_hi = e0;
-            if (2 * q + 1 == D - 1) e_hi = e1;
-          }
-        }
-        soff_c = soff_n;
-        gs = gs + 2 >= NGS ? gs + 2 - NGS : gs + 2;
-      }
-    }
-  };
-  // steady steps: 1 <= q and 2 (q + P) + 3 <= D - 1: the steady body requests gy planes 2(q+P)+1, +2 and x pair q + P and
-  // advances its pointers unconditionally, so the NEXT plane / pair must exist as well (the general body re-requests through
-  // the same pointers; one plane past the end of the last batch element is a fault once a plane spans whole pages -- seen at
-  // 528x960, silent at 240x624)
-  int qh = (D - 2 - 2 * P) >> 1;
-  if (npair - P - 1 < qh) qh = npair - P - 1;
-  int q0 = 0;
-  for (; q0 < npair && q0 < 1; q0 += U) group(std::false_type{}, q0);
-  for (; q0 + U <= qh; q0 += U) group(std::true_type{}, q0);
-  for (; q0 < npair; q0 += U) group(std::false_type{}, q0);
-  GA_VMCNT(0);      // no copy may still be in flight when the wave's LDS is handed to the next workgroup
-
-  // Everything the write-out needs about the pixel is recomputed here from an opaque copy of the lane id: kept live
-  // across the march it costs ~10 of the registers the 4 K accumulators leave (the kernel spilled in its inner loop).
-  {
-    int lane2 = threadIdx.x;
-#if !defined(GA_HIPSIM)
-    asm volatile("" : "+v"(lane2));
-#endif
-    const int i_ = ty0 + lane2 / LGA_TW, j_ = tx0 + lane2 % LGA_TW;
-    if (i_ < geo.H && j_ < geo.W) {
-      float *gfp = gf + (i64)b * 3 * K * geo.HW + (i64)i_ * geo.W + j_;
-#pragma unroll
-      for (int dd = 0; dd < 3; dd++) {
-        // accumulate mode: the K old values of this depth slab are loaded together, then added and stored
-        float old[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) old[k] = 0.f;
-        if (accumulate) {
-#pragma unroll
-          for (int k = 0; k < K; k++) old[k] = gfp[(i64)(dd * K + k) * geo.HW];
-        }
-#pragma unroll
-        for (int a = -R; a <= R; a++) {
-#pragma unroll
-          for (int bb = -R; bb <= R; bb++) {
-            const int t = dd * K + (a + R) * WS + (bb + R);
-            const int i2 = i_ + a, j2 = j_ + bb;
-            const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
-            float r;
-            if (dd == 0) r = Pq[a + R][bb + R].x + e_lo;
-            else if (dd == 1) r = Pq[a + R][bb + R].y;
-            else r = Qq[a + R][bb + R].x + Qq[a + R][bb + R].y + e_hi;
-            if (!ok) r = gc;
-            gfp[(i64)t * geo.HW] = old[(a + R) * WS + (bb + R)] + r;
-          }
-        }
-      }
-    }
-  }
-}
+#define GA_FG_NAME lga_filter_grad_pp
+#define GA_FG_XP 0
+#define GA_FG_SLOT PC::SLOT
+#define GA_FG_NDC ND
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+// x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
+#define GA_FG_NAME lga_filter_grad_pp_xp
+#define GA_FG_XP 1
+#define GA_FG_SLOT 512
+#define GA_FG_NDC 2
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 
 // one 4-byte global -> LDS copy per lane: lane l's dword lands at slot + 4 * l
 GA_DEV void lga_dma4(const float *gsrc, float *slot, int lane)

@@ -132,6 +132,13 @@ def _lga_dims(input, filters, radius):
     return B, D, H, W
 
 
+def _paired_intermediate(passes, radius, W):
+    """GANET_LGA_PAIRED=1 (default off: built and checked on the kernel emulator, not yet measured on a GPU): a two-pass
+    chain keeps its private intermediate volume pair-interleaved (include/ganet_hip.h, ganet_lga_apply_paired), which the second
+    pass and the filter gradient stage with two 16-byte copies per plane pair instead of seven 4-byte ones."""
+    return passes == 2 and radius == 2 and W % 2 == 0 and os.environ.get("GANET_LGA_PAIRED", "0") == "1"
+
+
 class _LgaChain(Function):
     """`passes` chained LGA passes sharing one filter tensor.  Backward walks the passes in
     reverse, accumulating gradFilters (functions/GANet.py:189-203, 68-83)."""
@@ -142,6 +149,21 @@ class _LgaChain(Function):
         _check(input, filters)
         ctx.radius = radius
         B, D, H, W = _lga_dims(input, filters, radius)
+        ctx.paired = False
+        if _paired_intermediate(cls.passes, radius, W):
+            with torch.cuda.device_of(input):
+                t1p = torch.empty(B * ((D + 1) // 2) * H * W * 2, dtype=input.dtype, device=input.device)
+                y = torch.empty_like(input)
+                try:
+                    _lib().call("ganet_lga_apply_paired", _p(input), _p(filters), _p(t1p), B, D, H, W, radius, 0, 0, 1, _stream())
+                    _lib().call("ganet_lga_apply_paired", _p(t1p), _p(filters), _p(y), B, D, H, W, radius, 0, 1, 0, _stream())
+                    ctx.paired = True
+                except _native.GanetError as e:
+                    if e.code != _native.E_UNSUPPORTED:
+                        raise
+            if ctx.paired:
+                ctx.save_for_backward(filters, input, t1p)
+                return y
         ins = [input]
         with torch.cuda.device_of(input):
             for _ in range(cls.passes):
@@ -157,6 +179,16 @@ class _LgaChain(Function):
         g = gradOutput.contiguous()
         _check(g)
         B, D, H, W = _lga_dims(ins[0], filters, ctx.radius)
+        if getattr(ctx, "paired", False):
+            x, t1p = ins
+            with torch.cuda.device_of(g):
+                gradFilters = torch.empty_like(filters)
+                gt1, gx = torch.empty_like(x), torch.empty_like(x)
+                lib, st = _lib(), _stream()
+                lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, ctx.radius, 0, st)
+                lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1), B, D, H, W, ctx.radius, 1, 0, 0, st)
+                lib.call("ganet_lga_backward", _p(x), _p(filters), _p(gt1), _p(gx), _p(gradFilters), B, D, H, W, ctx.radius, 1, st)
+            return gx, gradFilters, None
         with torch.cuda.device_of(g):
             gradFilters = torch.empty_like(filters)
             for k, xin in enumerate(reversed(ins)):

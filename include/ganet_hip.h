@@ -143,12 +143,18 @@ int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *s
  * y the input gradient, as the second half of ganet_lga_backward) on volumes in the PAIR-INTERLEAVED layout
  * [B][ceil(D/2)][H][W][2] -- planes 2m and 2m+1 of a pixel adjacent; for odd D the odd half of the last pair is zero (written
  * so by this entry when y is interleaved; required of x when x is interleaved).  x_paired / y_paired select the layout of
- * either side; exactly one of them must be set.  The layout is for volumes that never cross the operator API: the
+ * either side; at most one of them (neither: the API-layout pass or data-backward on its own).  The layout is for volumes that never cross the operator API: the
  * intermediate between the two passes of an LGA2 (functions/GANet.py:176-187) and its gradient -- a consumer stages a plane
  * pair with two 16-byte copies per lane instead of seven 4-byte ones, a producer stores a pair with one 8-byte store.
  * radius 2 only, W even, 16-byte aligned volumes; GANET_E_UNSUPPORTED otherwise (use the API-layout entries). */
 int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, int radius,
                            int transposed, int x_paired, int y_paired, void *stream);
+
+/* ABI v7.  The filter gradient of one LGA pass (the first half of ganet_lga_backward: lga_filter_backward,
+ * GANet_kernel.cu:1177-1216) with x in the pair-interleaved layout (see ganet_lga_apply_paired); gy and gf keep the API
+ * layout; gf written (accumulate_gf = 0) or accumulated into.  radius 2 only, W even, x 16-byte aligned. */
+int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
+                                 int accumulate_gf, void *stream);
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,
@@ -241,6 +247,9 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
  *   GANET_SGA_WIDE_SCAN=0|1|2  scans with the whole wavefront on one scanline: never | for inputs with few scanlines and for
  *                         D > 272 (default) | whenever D > 48
+ *   GANET_LGA_PAIRED=0|1  (read by ganet_amd.functions.GANet, not by this library) Lga2Function keeps its intermediate volume
+ *                         pair-interleaved (ganet_lga_apply_paired).  Default 0: checked on the CPU emulator, not yet measured
+ *                         on a GPU (scripts/check_lga_paired.py)
  *   GANET_SGA_WIDE_COL=0|1  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
  *                         D <= 192; for inputs with few column blocks).  Default 0: checked on the CPU emulator, not yet
  *                         measured on a GPU (scripts/check_wide_col.py)

@@ -211,10 +211,64 @@ def test_apply_on_pair_interleaved_volumes(sim, port_oracle, shape, mode):
 def test_apply_paired_argument_errors(sim):
     from ganet_amd._native import GanetError
     x = DEV.zeros((1, 4, 2, 4))
-    with pytest.raises(GanetError, match="exactly one"):
+    with pytest.raises(GanetError, match="at most one"):
         sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 4))), 1, 4, 2, 4, 2, 0, 1, 1, None)
     with pytest.raises(GanetError, match="radius 2"):
         sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 4))), 1, 4, 2, 4, 1, 0, 1, 0, None)
     with pytest.raises(GanetError, match="W even"):
         sim.call("ganet_lga_apply_paired", DEV.ptr(x), DEV.ptr(x), DEV.ptr(DEV.zeros((1, 4, 2, 3))), 1, 4, 2, 3, 2, 0, 1, 0, None)
 
+
+
+@pytest.mark.parametrize("mode", ["guard_end", "guard_start", "late_reversed"])
+@pytest.mark.parametrize("wps", [3, 2])
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 1, 3, 34), (1, 2, 2, 2), (1, 26, 2, 6),
+                                   (1, 40, 3, 32), (1, 41, 7, 64)])
+def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, wps, mode):
+    """ganet_lga_filter_grad_paired (ABI v7): gf of one pass with x in the pair-interleaved layout, write and accumulate
+    mode, both register budgets of the kernel."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(sum(shape) + wps)
+    x = rng.standard_normal(shape).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    _, want = port_oracle.lga_backward(x, f, gy, 2)
+    dev = pc.NumpyDev("start" if mode == "guard_start" else "end")
+    sim.set_option("GANET_LGA_FG_WPS", wps)
+    if mode == "late_reversed":
+        sim.set_option("HIPSIM_LATE_DMA", 1)
+        sim.set_option("HIPSIM_LANE_ORDER", 1)
+    try:
+        xp, dgy, gf = dev.to(pc.to_paired(x)), dev.to(gy), dev.empty(f.shape)
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, None)
+        assert np.abs(gf - want).max() < 3e-5
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, None)
+        assert np.abs(gf - 2 * want).max() < 6e-5
+    finally:
+        sim.set_option("GANET_LGA_FG_WPS", 3)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+        sim.set_option("HIPSIM_LANE_ORDER", 0)
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2)])
+def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape):
+    """The call sequence of Lga2Function with GANET_LGA_PAIRED=1 (ganet_amd/functions/GANet.py: _LgaChain): forward
+    x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 = gX(gy); (gx, gf +=) = backward(x, g_t1)."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    y_want, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+    gx_want, gf_want = port_oracle.lga_chain_backward(ins, f, gy, 2)
+    dev = DEV
+    dx, df, dgy = dev.to(x), dev.to(f), dev.to(gy)
+    t1p, y = dev.empty((B, (D + 1) // 2, H, W, 2)), dev.empty(shape)
+    sim.call("ganet_lga_apply_paired", dev.ptr(dx), dev.ptr(df), dev.ptr(t1p), B, D, H, W, 2, 0, 0, 1, None)
+    sim.call("ganet_lga_apply_paired", dev.ptr(t1p), dev.ptr(df), dev.ptr(y), B, D, H, W, 2, 0, 1, 0, None)
+    assert np.abs(y - y_want).max() < 2e-5
+    gf, gt1, gx = dev.empty(f.shape), dev.empty(shape), dev.empty(shape)
+    sim.call("ganet_lga_filter_grad_paired", dev.ptr(t1p), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, None)
+    sim.call("ganet_lga_apply_paired", dev.ptr(dgy), dev.ptr(df), dev.ptr(gt1), B, D, H, W, 2, 1, 0, 0, None)
+    sim.call("ganet_lga_backward", dev.ptr(dx), dev.ptr(df), dev.ptr(gt1), dev.ptr(gx), dev.ptr(gf), B, D, H, W, 2, 1, None)
+    assert np.abs(gx - gx_want).max() < 2e-5 and np.abs(gf - gf_want).max() < 5e-5
