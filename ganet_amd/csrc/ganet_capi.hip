@@ -676,10 +676,11 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   return check_launch("lga apply (plane pairs, interleaved volume)");
 }
 
-int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc, hipStream_t st)
+int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int acc, bool x_paired,
+                         hipStream_t st)
 {
-  if ((i64)H * W >= (1ll << 28) || W % 2 != 0 || !aligned16(x))
-    return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: needs W even, planes below 2^28 pixels and a 16-byte aligned x");
+  if ((i64)H * W >= (1ll << 28) || W % 2 != 0 || !aligned16(x) || !aligned16(gy))
+    return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: needs W even, planes below 2^28 pixels and 16-byte aligned volumes");
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   LgaSeg sg;
@@ -688,9 +689,15 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (opts().lga_fg_wps == 2) GA_LAUNCH((lga_filter_grad_pp_xp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  return check_launch("lga filter grad (plane pairs, interleaved x)");
+  const bool w2 = opts().lga_fg_wps == 2;
+  if (x_paired) {
+    if (w2) GA_LAUNCH((lga_filter_grad_pp_xp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+    else GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  } else {
+    if (w2) GA_LAUNCH((lga_filter_grad_pp_gyp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+    else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  }
+  return check_launch("lga filter grad (plane pairs, interleaved volume)");
 }
 
 // one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
@@ -1068,12 +1075,14 @@ GA_EXPORT int ganet_lga_apply_paired(const float *x, const float *f, float *y, i
 }
 
 GA_EXPORT int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
-                                           int accumulate_gf, void *stream)
+                                           int accumulate_gf, int x_paired, int gy_paired, void *stream)
 {
   if (!x || !gy || !gf) return fail(GANET_E_INVALID, "ganet_lga_filter_grad_paired: null pointer");
   GA_TRY(check_lga("ganet_lga_filter_grad_paired", B, D, H, W, radius));
+  if (x_paired && gy_paired) return fail(GANET_E_INVALID, "ganet_lga_filter_grad_paired: at most one of x_paired / gy_paired");
   if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: radius 2 only");
-  return launch_lga_gf_paired(x, gy, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
+  if (!x_paired && !gy_paired) return launch_lga_gf<2>(x, gy, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
+  return launch_lga_gf_paired(x, gy, gf, B, D, H, W, accumulate_gf != 0, x_paired != 0, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,

@@ -1092,21 +1092,38 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
 // the ones scripts/isa_lint.py finds spill-free inside the loop: (3, 0) and (2, 2) at R = 2.
 #define GA_FG_NAME lga_filter_grad_pp
 #define GA_FG_XP 0
+#define GA_FG_GYP 0
 #define GA_FG_SLOT PC::SLOT
 #define GA_FG_NDC ND
 #include "lga_filter_grad_pp.inc"
 #undef GA_FG_NAME
 #undef GA_FG_XP
+#undef GA_FG_GYP
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 // x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
 #define GA_FG_NAME lga_filter_grad_pp_xp
 #define GA_FG_XP 1
+#define GA_FG_GYP 0
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
 #undef GA_FG_NAME
 #undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+
+// gy pair-interleaved, x in the API layout (the filter gradient of the first pass of an LGA2)
+#define GA_FG_NAME lga_filter_grad_pp_gyp
+#define GA_FG_XP 0
+#define GA_FG_GYP 1
+#define GA_FG_SLOT PC::SLOT
+#define GA_FG_NDC ND
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 

@@ -183,11 +183,12 @@ class _LgaChain(Function):
             x, t1p = ins
             with torch.cuda.device_of(g):
                 gradFilters = torch.empty_like(filters)
-                gt1, gx = torch.empty_like(x), torch.empty_like(x)
-                lib, st = _lib(), _stream()
-                lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, ctx.radius, 0, st)
-                lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1), B, D, H, W, ctx.radius, 1, 0, 0, st)
-                lib.call("ganet_lga_backward", _p(x), _p(filters), _p(gt1), _p(gx), _p(gradFilters), B, D, H, W, ctx.radius, 1, st)
+                gt1p, gx = torch.empty_like(t1p), torch.empty_like(x)      # the intermediate's gradient is private too
+                lib, st, r = _lib(), _stream(), ctx.radius
+                lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, r, 0, 1, 0, st)
+                lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1p), B, D, H, W, r, 1, 0, 1, st)
+                lib.call("ganet_lga_filter_grad_paired", _p(x), _p(gt1p), _p(gradFilters), B, D, H, W, r, 1, 0, 1, st)
+                lib.call("ganet_lga_apply_paired", _p(gt1p), _p(filters), _p(gx), B, D, H, W, r, 1, 1, 0, st)
             return gx, gradFilters, None
         with torch.cuda.device_of(g):
             gradFilters = torch.empty_like(filters)

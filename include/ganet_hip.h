@@ -151,10 +151,11 @@ int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int 
                            int transposed, int x_paired, int y_paired, void *stream);
 
 /* ABI v7.  The filter gradient of one LGA pass (the first half of ganet_lga_backward: lga_filter_backward,
- * GANet_kernel.cu:1177-1216) with x in the pair-interleaved layout (see ganet_lga_apply_paired); gy and gf keep the API
- * layout; gf written (accumulate_gf = 0) or accumulated into.  radius 2 only, W even, x 16-byte aligned. */
+ * GANet_kernel.cu:1177-1216) with x OR gy in the pair-interleaved layout (see ganet_lga_apply_paired; at most one of
+ * x_paired / gy_paired, neither: the API layout); gf keeps the API layout and is written (accumulate_gf = 0) or accumulated
+ * into.  radius 2 only, W even, 16-byte aligned volumes. */
 int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
-                                 int accumulate_gf, void *stream);
+                                 int accumulate_gf, int x_paired, int gy_paired, void *stream);
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,

@@ -240,9 +240,15 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, wps, mod
         sim.set_option("HIPSIM_LANE_ORDER", 1)
     try:
         xp, dgy, gf = dev.to(pc.to_paired(x)), dev.to(gy), dev.empty(f.shape)
-        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, None)
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, 1, 0, None)
         assert np.abs(gf - want).max() < 3e-5
-        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, None)
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, 1, 0, None)
+        assert np.abs(gf - 2 * want).max() < 6e-5
+        # gy interleaved instead (x in the API layout), and neither
+        dx, gyp = dev.to(x), dev.to(pc.to_paired(gy))
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(gyp), dev.ptr(gf), B, D, H, W, 2, 0, 0, 1, None)
+        assert np.abs(gf - want).max() < 3e-5
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, 0, 0, None)
         assert np.abs(gf - 2 * want).max() < 6e-5
     finally:
         sim.set_option("GANET_LGA_FG_WPS", 3)
@@ -253,7 +259,7 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, wps, mod
 @pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2)])
 def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape):
     """The call sequence of Lga2Function with GANET_LGA_PAIRED=1 (ganet_amd/functions/GANet.py: _LgaChain): forward
-    x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 = gX(gy); (gx, gf +=) = backward(x, g_t1)."""
+    x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 (interleaved) = gX(gy); gf += gF(x, g_t1); gx = gX(g_t1)."""
     B, D, H, W = shape
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
@@ -267,8 +273,9 @@ def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, sha
     sim.call("ganet_lga_apply_paired", dev.ptr(dx), dev.ptr(df), dev.ptr(t1p), B, D, H, W, 2, 0, 0, 1, None)
     sim.call("ganet_lga_apply_paired", dev.ptr(t1p), dev.ptr(df), dev.ptr(y), B, D, H, W, 2, 0, 1, 0, None)
     assert np.abs(y - y_want).max() < 2e-5
-    gf, gt1, gx = dev.empty(f.shape), dev.empty(shape), dev.empty(shape)
-    sim.call("ganet_lga_filter_grad_paired", dev.ptr(t1p), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, None)
-    sim.call("ganet_lga_apply_paired", dev.ptr(dgy), dev.ptr(df), dev.ptr(gt1), B, D, H, W, 2, 1, 0, 0, None)
-    sim.call("ganet_lga_backward", dev.ptr(dx), dev.ptr(df), dev.ptr(gt1), dev.ptr(gx), dev.ptr(gf), B, D, H, W, 2, 1, None)
+    gf, gt1p, gx = dev.empty(f.shape), dev.empty((B, (D + 1) // 2, H, W, 2)), dev.empty(shape)
+    sim.call("ganet_lga_filter_grad_paired", dev.ptr(t1p), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, 1, 0, None)
+    sim.call("ganet_lga_apply_paired", dev.ptr(dgy), dev.ptr(df), dev.ptr(gt1p), B, D, H, W, 2, 1, 0, 1, None)
+    sim.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(gt1p), dev.ptr(gf), B, D, H, W, 2, 1, 0, 1, None)
+    sim.call("ganet_lga_apply_paired", dev.ptr(gt1p), dev.ptr(df), dev.ptr(gx), B, D, H, W, 2, 1, 1, 0, None)
     assert np.abs(gx - gx_want).max() < 2e-5 and np.abs(gf - gf_want).max() < 5e-5
