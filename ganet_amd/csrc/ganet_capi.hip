@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> gd_h{16};
   std::atomic<int> streams{0};
   std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
+  std::atomic<int> lga_mix{0};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 = off (not measured yet)
   std::atomic<int> wide_col{0};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks); 0 = off (not measured yet)
   std::atomic<int> wide_scan{1};    // SGA scans with the whole wavefront on one scanline: 1 for inputs with few scanlines (and D > 272), 0 never, 2 whenever D > 48 (tests)
   std::atomic<int> lga_bwd_streams{0};   // 1: filter gradient and data-backward of an LGA backward pass on two streams
@@ -99,6 +100,7 @@ void load_env_options()
   geti("GANET_LGA_BWD_STREAMS", g_opt.lga_bwd_streams);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
+  geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
@@ -623,6 +625,29 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
         sg.seg_len = (sg.seg_len + 1) & ~1;
         sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
       }
+      if constexpr (R == 2) {
+        // mixed item list (GANET_LGA_MIX, see LgaSegMix): q whole tiles per SIMD + at most one segment of the remaining ones
+        const int mixo = opts().lga_mix;
+        const i64 S = mixo > 1 ? (i64)mixo : (i64)4 * device_cus();
+        if (mixo && opts().lga_segs <= 0 && tiles < (1ll << 30) && tiles / S < LGA_WAVES_PER_SIMD && tiles % S != 0) {
+          const i64 r = tiles % S;
+          int nsub = (int)(S / r);
+          if (nsub > D / 16) nsub = D / 16;
+          if (nsub >= 2) {
+            LgaSegMix mx;
+            mx.tiles_x = sg.tiles_x; mx.tiles_y = sg.tiles_y;
+            mx.n_whole = (int)(tiles - r);
+            mx.sub_len = ((D + nsub - 1) / nsub + 1) & ~1;
+            mx.nsub = (D + mx.sub_len - 1) / mx.sub_len;
+            const i64 items_mx = mx.n_whole + r * mx.nsub;
+            if (transposed) GA_LAUNCH((lga_apply_pp_mix<R, true>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
+            else GA_LAUNCH((lga_apply_pp_mix<R, false>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
+            static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;
+            if (trace) fprintf(stderr, "[ganet] lga_apply_pp_mix T=%d whole=%d + %lld x %d segments of %d planes\n", (int)transposed, mx.n_whole, (long long)r, mx.nsub, mx.sub_len);
+            return check_launch("lga apply (plane pairs, mixed item list)");
+          }
+        }
+      }
       const i64 items_pp = tiles * sg.nseg;
       if constexpr (R <= 2) if (items_pp < (1ll << 31)) {
         if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
@@ -827,6 +852,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_BWD_STREAMS")) g_opt.lga_bwd_streams = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;

@@ -1006,6 +1006,8 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 
 // ---- lga_apply_pp (API layout in, API layout out) and its pair-interleaved forms: lga_apply_pp.inc --------------------------
 #define GA_PP_NAME lga_apply_pp
+#define GA_PP_SEG_T LgaSeg
+#define GA_PP_DECODE lga_decode_item
 #define GA_PP_IN 0
 #define GA_PP_OUT 0
 #define GA_PP_SLOT PC::SLOT
@@ -1013,6 +1015,56 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
 #undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+
+// ---- MIXED item list: most tiles whole, the rest cut into depth segments -----------------------------------------------------
+// These kernels are bound by VALU issue and the waves of a SIMD share one VALU, so a pass lasts as long as the SIMD with the
+// most resident work: 2,400 tiles on 1,024 SIMDs are 2 or 3 tiles per SIMD and the pass takes the time of 3 (the FMA-only
+// ablation runs exactly 3 x 97 x 75 packed FMAs x 4 clk = 36 us), although the average is 2.34.  Cutting EVERY tile in
+// two was measured slower (each item gathers its 75 taps and fills its pipeline again).  Here only the T mod S tiles
+// beyond a whole number per SIMD are cut, into nsub segments with T mod S x nsub <= S: items [0, n_whole) are whole tiles --
+// dispatched first, q per SIMD -- and the rest are the segments, at most one per SIMD.
+struct LgaSegMix {
+  int tiles_x, tiles_y;
+  int n_whole;        // whole tiles (items [0, n_whole)), then nsub items per remaining tile
+  int nsub, sub_len;  // sub_len even
+};
+GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, int &b, int &d_lo, int &d_hi)
+{
+  int item = (int)blockIdx.x;
+  if (item < sg.n_whole) {
+    item = xcd_remap(item, sg.n_whole);
+    d_lo = 0;
+    d_hi = D;
+  } else {
+    const int idx = item - sg.n_whole;
+    const int seg = idx % sg.nsub;
+    item = sg.n_whole + idx / sg.nsub;
+    d_lo = seg * sg.sub_len;
+    d_hi = d_lo + sg.sub_len < D ? d_lo + sg.sub_len : D;
+  }
+  bx = item % sg.tiles_x; item /= sg.tiles_x;
+  by = item % sg.tiles_y;
+  b = item / sg.tiles_y;
+}
+#define GA_PP_NAME lga_apply_pp_mix
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 0
+#define GA_PP_OUT 0
+#define GA_PP_SLOT PC::SLOT
+#define GA_PP_NDC ND
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
 #undef GA_PP_IN
 #undef GA_PP_OUT
 #undef GA_PP_SLOT
@@ -1022,6 +1074,8 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
 // API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
 #define GA_PP_NAME lga_apply_pp_po
+#define GA_PP_SEG_T LgaSeg
+#define GA_PP_DECODE lga_decode_item
 #define GA_PP_IN 0
 #define GA_PP_OUT 1
 #define GA_PP_SLOT PC::SLOT
@@ -1029,6 +1083,8 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
 #undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
 #undef GA_PP_IN
 #undef GA_PP_OUT
 #undef GA_PP_SLOT
@@ -1036,6 +1092,8 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #undef GA_PP_Y
 // pair-interleaved in, API layout out (second pass of an LGA2; data-backward of its first pass)
 #define GA_PP_NAME lga_apply_pp_pi
+#define GA_PP_SEG_T LgaSeg
+#define GA_PP_DECODE lga_decode_item
 #define GA_PP_IN 1
 #define GA_PP_OUT 0
 #define GA_PP_SLOT 512
@@ -1043,6 +1101,8 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
 #undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
 #undef GA_PP_IN
 #undef GA_PP_OUT
 #undef GA_PP_SLOT

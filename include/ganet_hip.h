@@ -248,6 +248,10 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
  *   GANET_SGA_WIDE_SCAN=0|1|2  scans with the whole wavefront on one scanline: never | for inputs with few scanlines and for
  *                         D > 272 (default) | whenever D > 48
+ *   GANET_LGA_MIX=0|1     plane-pair forward / data-backward with a MIXED item list: whole tiles first (a whole number per
+ *                         SIMD), the remaining tiles cut into depth segments, at most one segment per SIMD -- the waves of a
+ *                         SIMD share one VALU, so a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average
+ *                         at 240x624).  Default 0: checked on the CPU emulator, not yet measured on a GPU
  *   GANET_LGA_PAIRED=0|1  (read by ganet_amd.functions.GANet, not by this library) Lga2Function keeps its intermediate volume
  *                         pair-interleaved (ganet_lga_apply_paired).  Default 0: checked on the CPU emulator, not yet measured
  *                         on a GPU (scripts/check_lga_paired.py)

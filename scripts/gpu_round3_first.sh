@@ -4,6 +4,7 @@
 # 1. pytest -m gpu (ops) -- the state the round starts from
 # 2. scripts/check_lga_paired.py   GANET_LGA_PAIRED=1: Lga2Function parity on vs off + timing (kernels lga_apply_pp_pi/_po, lga_filter_grad_pp_xp/_gyp)
 # 3. bench.py with GANET_LGA_PAIRED=0 and =1 (same box A/B of the headline number)
+# 3b. bench.py with GANET_LGA_MIX=1 (mixed item list), alone and with PAIRED; LGA parity tests under GANET_LGA_MIX=1
 # 4. scripts/check_wide_col.py     GANET_SGA_WIDE_COL=1: parity + timing of the vertical scans on the stress shape
 TAG=${1:-r3a}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -28,6 +29,19 @@ for k in (0, 1):
     except Exception as e:
         print("GANET_LGA_PAIRED=%d: no result (%r)" % (k, e))
 PY
+echo "== bench, GANET_LGA_MIX=1 (mixed item list of the plane-pair forward / data-backward), and MIX + PAIRED"
+GANET_LGA_MIX=1 timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_mix1.json 2> $OUT/bench_mix1.err; echo "rc=$?"
+GANET_LGA_MIX=1 GANET_LGA_PAIRED=1 timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_mix1_paired1.json 2> $OUT/bench_mix1_paired1.err; echo "rc=$?"
+python - <<PY
+import json
+for k in ("mix1", "mix1_paired1"):
+    try:
+        d = json.load(open("$OUT/bench_%s.json" % k))
+        print("%s: %.1f cv/s  %.4f ms per step; stage lga fwd %.4f bwd %.4f" % (k, d["value"], d["ms_per_step"], d["stage_ms"]["lga_fwd_pass"], d["stage_ms"]["lga_bwd_pass"]))
+    except Exception as e:
+        print("%s: no result (%r)" % (k, e))
+PY
+GANET_LGA_MIX=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "lga" > $OUT/pytest_lga_mix.txt 2>&1; echo "lga parity with GANET_LGA_MIX=1 rc=$?"; tail -2 $OUT/pytest_lga_mix.txt
 echo "== wide column blocks"
 timeout 600 python scripts/check_wide_col.py > $OUT/check_wide_col.txt 2>&1; echo "rc=$?"; grep -v amdgpu.ids $OUT/check_wide_col.txt | tail -20
 echo "== done"

@@ -279,3 +279,25 @@ def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, sha
     sim.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(gt1p), dev.ptr(gf), B, D, H, W, 2, 1, 0, 1, None)
     sim.call("ganet_lga_apply_paired", dev.ptr(gt1p), dev.ptr(df), dev.ptr(gx), B, D, H, W, 2, 1, 1, 0, None)
     assert np.abs(gx - gx_want).max() < 2e-5 and np.abs(gf - gf_want).max() < 5e-5
+
+
+@pytest.mark.parametrize("simds", [2, 3, 5, 7])
+@pytest.mark.parametrize("shape", [(1, 40, 6, 64), (2, 33, 5, 68), (1, 64, 9, 36), (1, 47, 2, 100)])
+def test_mixed_item_list_of_the_plane_pair_apply(sim, port_oracle, shape, simds):
+    """GANET_LGA_MIX (LgaSegMix): whole tiles first, the tiles beyond a whole number per SIMD cut into depth segments --
+    forward and data-backward equal to the oracle whatever the SIMD count assumed (2..7 here; late-landing copies on)."""
+    B, D, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    y = port_oracle.lga_forward(x, f, 2)
+    gx, gf = port_oracle.lga_backward(x, f, gy, 2)
+    sim.set_option("GANET_LGA_MIX", simds)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        err = pc.check_lga_chain(sim, pc.NumpyDev("start" if simds % 2 else "end"), x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
+        assert max(err.values()) < 2e-5, err
+    finally:
+        sim.set_option("GANET_LGA_MIX", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
