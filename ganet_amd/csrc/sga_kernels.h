@@ -33,6 +33,10 @@
 #pragma once
 #include "ga_common.h"
 
+#ifndef GA_SCAN_ABLATE
+#define GA_SCAN_ABLATE 0     // A/B builds only (scripts/build_variants.py): 1 = the tile path of the LDS-staged scans without the recurrence
+#endif
+
 namespace ga {
 
 // One traversal over [S slices][D][H][W] (+ guidance [S][5][H][W]), in VISIT order

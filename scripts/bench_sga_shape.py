@@ -6,6 +6,8 @@ import torch
 import torch.nn.functional as F
 from ganet_amd import _native
 N, C, D, H, W = (int(v) for v in sys.argv[1:6])
+if os.environ.get('GANET_VARIANT_LIB'):
+    _native._LIB = _native.CApi(os.path.join(ROOT, 'ganet_amd', os.environ['GANET_VARIANT_LIB']))      # A/B builds of scripts/build_variants.py
 lib = _native.lib()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)

@@ -9,4 +9,4 @@ for name in sys.argv[1:]:
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
     inp = bench.make_inputs(torch.device("cuda:0"))
     st = bench.stage_timings(inp, iters=10)
-    print(name, {k: round(v, 4) for k, v in st.items() if k in ("sga_scan_fwd_down", "sga_scan_fwd_up", "sga_bwd_scan_down", "sga_bwd_scan_up")}, flush=True)
+    print(name, {k: round(v, 4) for k, v in st.items() if k.startswith("sga_")}, flush=True)
