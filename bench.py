@@ -11,11 +11,15 @@ fp32, synthetic inputs resident in HBM before the timed region, torch.manual_see
 N > 1 is launched by the driver as torch.distributed.run, one rank per GPU (without a launcher this file re-executes
 itself that way); ranks run independent cost volumes (the ops have no cross-sample term, so there is no data-path
 collective; the barrier / max-over-ranks timing protocol runs over gloo on the host): weak scaling,
-value = N*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
+value = N*K / max-over-ranks time.  After the timed region the ranks run the one collective a data-parallel caller of this
+path has -- the 26.3 MB fp32 gradient all-reduce of GANet-deep -- over RCCL and report it as `rccl` (never part of
+`value`).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      HBM roofline of the dominant kernel family (largest share of the step), from
-                per-stage HIP-event timings taken on the launch stream after the timed region
+  roofline      the dominant kernel family (largest share of the step) against its BINDING bound -- HBM bandwidth for the
+                SGA families, fp32 FMA rate for the LGA families -- from per-stage HIP-event timings taken on
+                the launch stream after the timed region; `families` lists every family with both fractions; the unit's
+                measured traffic (PMC) beside its algorithmic bytes
   cpu_baseline  the CPU checker (oracle/_ref = the reference's own kernel bodies when the prebuilt
                 .so is present, else the C restatement) timed on this box's host cores on ONE
                 cost volume of the same workload
@@ -143,11 +147,27 @@ def stage_timings(inp, iters=5):
         kp.data_ptr(), go.data_ptr(), G.data_ptr(), gx.data_ptr(), *[g.data_ptr() for g in gw],
         N, C, D, H, W, st))
     res["sga_bwd_point"] = res["sga_backward_call"] - sum(res[f"sga_bwd_scan_{n}"] for n in names)
-    res["lga_fwd_pass"] = timed(lambda: lib.call(
-        "ganet_lga_forward", xl.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, RADIUS, st))
-    res["lga_bwd_pass"] = timed(lambda: lib.call(
-        "ganet_lga_backward", xl.data_ptr(), f.data_ptr(), gy.data_ptr(), gxl.data_ptr(), gf.data_ptr(),
-        B, DL, HL, WL, RADIUS, 0, st))
+    # LGA2 as Lga2Function runs it: the private intermediate and its gradient pair-interleaved (functions/GANet.py: _LgaChain)
+    tp = torch.empty(B * ((DL + 1) // 2) * HL * WL * 2, device=xl.device)
+    gtp = torch.empty_like(tp)
+    p = lambda t: t.data_ptr()      # noqa: E731
+
+    def lga2_fwd():
+        lib.call("ganet_lga_apply_paired", p(xl), p(f), p(tp), B, DL, HL, WL, RADIUS, 0, 0, 1, st)
+        lib.call("ganet_lga_apply_paired", p(tp), p(f), p(y), B, DL, HL, WL, RADIUS, 0, 1, 0, st)
+
+    def lga2_bwd():
+        lib.call("ganet_lga_filter_grad_paired", p(tp), p(gy), p(gf), B, DL, HL, WL, RADIUS, 0, 1, 0, st)
+        lib.call("ganet_lga_apply_paired", p(gy), p(f), p(gtp), B, DL, HL, WL, RADIUS, 1, 0, 1, st)
+        lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)
+        lib.call("ganet_lga_apply_paired", p(gtp), p(f), p(gxl), B, DL, HL, WL, RADIUS, 1, 1, 0, st)
+    res["lga_fwd_pass"] = timed(lga2_fwd) / 2                # average of the two passes of the chain
+    res["lga_bwd_pass"] = timed(lga2_bwd) / 2                # (filter gradient + data-backward) x 2
+    # one pass on the API layout (LgaFunction, the last pass of DispAggTail): for comparison with earlier rounds
+    res["lga_fwd_pass_api_layout"] = timed(lambda: lib.call(
+        "ganet_lga_forward", p(xl), p(f), p(t1), B, DL, HL, WL, RADIUS, st))
+    res["lga_bwd_pass_api_layout"] = timed(lambda: lib.call(
+        "ganet_lga_backward", p(xl), p(f), p(gy), p(gxl), p(gf), B, DL, HL, WL, RADIUS, 0, st))
     return res
 
 
@@ -159,8 +179,9 @@ _FAMILY_KERNELS = {
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
                      ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false>"]],
-    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp<2, 3, 0>", "lga_apply_pp<2, true, false>"]],
-    "lga_apply (fwd pass)": [["lga_apply_pp<2, false, false>"]],
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_xp<2, 3, 0>", "lga_apply_pp_po<2, true, false>"],
+                                         ["lga_filter_grad_pp_gyp<2, 3, 0>", "lga_apply_pp_pi<2, true, false>"]],
+    "lga_apply (fwd pass)": [["lga_apply_pp_po<2, false, false>"], ["lga_apply_pp_pi<2, false, false>"]],
 }
 
 
@@ -212,28 +233,45 @@ def roofline_from_stages(stages):
     }
     kern = pmc_traffic()
     table, best, best_t = [], None, -1.0
+    unit_traffic = 0
     for name, (keys, bytes_per_launch, mult) in fam.items():
         avg_ms = sum(stages[k] for k in keys) / len(keys)
         step_ms = sum(stages[k] for k in keys) * mult
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = _family_traffic(name, kern)
         row = {"kernel": name, "launches_per_step": len(keys) * mult, "avg_launch_ms": round(avg_ms, 4),
-               "alg_bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 1),
-               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _family_traffic(name, kern)}
+               "step_ms": round(step_ms, 4), "bound": "hbm", "frac": round(achieved / HBM_PEAK_GBS, 4),
+               "alg_bytes_per_launch": int(bytes_per_launch), "hbm_GBs": round(achieved, 1),
+               "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if traffic is not None and unit_traffic is not None:
+            unit_traffic += traffic * len(keys) * mult
+        else:
+            unit_traffic = None
         if name in _FAMILY_FLOPS:
-            # LGA is the one family whose arithmetic bound (fp32 VALU = fp32 MFMA rate, 157.3 TFLOP/s) lies above its
-            # HBM bound (27.6 flop/B): report it against that peak as well
+            # the LGA families' binding bound is arithmetic (fp32 VALU = fp32 MFMA rate, 157.3 TFLOP/s; SURVEY 8d: 27.6 flop/B
+            # lies above the ridge of 19.7): `frac` is the fp32 fraction, the HBM fraction stays alongside
             tf = _FAMILY_FLOPS[name] / (avg_ms * 1e-3) / 1e12
+            row["bound"] = "fp32"
             row["fp32_tflops"] = round(tf, 1)
             row["fp32_frac"] = round(tf / FP32_PEAK_TFLOPS, 4)
+            row["frac"] = row["fp32_frac"]
         table.append(row)
         if step_ms > best_t:
             best, best_t = row, step_ms
-    return {"bound": "hbm", "kernel": best["kernel"], "achieved": best["achieved"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": best["frac"], "alg_bytes_per_launch": best["alg_bytes_per_launch"],
-            "avg_launch_ms": best["avg_launch_ms"], "traffic": best["traffic"],
-            "traffic_source": "profiles/traffic_pmc.json (rocprofv3 --pmc TCC_EA0 request counters x request size, "
-                              "bytes per launch, Infinity-Cache hits included)" if best["traffic"] else None,
-            "families": table}
+    fp32 = best["bound"] == "fp32"
+    out = {"bound": "fp32 (VALU)" if fp32 else "hbm", "kernel": best["kernel"],
+           "achieved": best["fp32_tflops"] if fp32 else best["hbm_GBs"], "peak": FP32_PEAK_TFLOPS if fp32 else HBM_PEAK_GBS,
+           "unit": "TFLOP/s" if fp32 else "GB/s", "frac": best["frac"],
+           "alg_flops_per_launch": int(_FAMILY_FLOPS[best["kernel"]]) if fp32 else None,
+           "alg_bytes_per_launch": best["alg_bytes_per_launch"], "hbm_GBs": best["hbm_GBs"], "hbm_frac": best["hbm_frac"],
+           "avg_launch_ms": best["avg_launch_ms"], "traffic": best["traffic"],
+           "traffic_source": "profiles/traffic_pmc.json (rocprofv3 --pmc TCC_EA0 request counters x request size, bytes per launch "
+                             "at the L2 <-> fabric boundary: Infinity-Cache hits included, so an upper bound of DRAM traffic)" if best["traffic"] else None,
+           "families": table}
+    if unit_traffic is not None:
+        out["unit_traffic_bytes"] = int(unit_traffic)
+        out["unit_traffic_ratio"] = round(unit_traffic / UNIT_BYTES, 3)
+    return out
 
 
 def cpu_baseline():
@@ -274,7 +312,7 @@ def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run,
     one rank per GPU, rendezvous on 127.0.0.1 (what the driver's own launch line does)."""
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for the RCCL probe after the timed region (task notes: the host driver supports no legacy IPC)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -305,6 +343,9 @@ def stub_main(args):
             "unit": "steps/sec", "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "stub"}
+    probe = gdist.allreduce_probe(ctx, "gloo", torch.device("cpu"), nelem=1 << 16, iters=2)
+    if probe is not None:
+        line["rccl"] = probe              # (the protocol test's stand-in for the RCCL probe of the real run)
     gdist.finish(ctx)
     if ctx.rank == 0:
         print(json.dumps(line))
@@ -463,6 +504,19 @@ def main():
             line["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
         if not args.no_cpu_baseline and ctx.world_size == 1:
             line["cpu_baseline"] = cpu_baseline()
+    if ctx.world_size > 1:
+        # The gradient all-reduce of a data-parallel caller (26.3 MB fp32 = GANet-deep's parameters) over RCCL / xGMI, AFTER
+        # the timed region and on every rank; an extra object, never part of `value` (the op metric has no collective).
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)                      # (RCCL / gloo may print on stdout)
+        try:
+            probe = gdist.allreduce_probe(ctx, os.environ.get("GANET_BENCH_COLLECTIVE", "nccl"), device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        line["rccl"] = probe
     gdist.finish(ctx)
     if ctx.rank == 0:
         print(json.dumps(line))

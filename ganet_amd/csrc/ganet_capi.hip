@@ -55,31 +55,17 @@ int check_launch(const char *what)
   } while (0)
 
 // ---- options ------------------------------------------------------------------
-// Defaults measured on MI355X at [1,32,65,80,208] (profiles/r1_tune_sga.txt): vertical scans
-// want FEW lanes per scanline (GD=4: each wave load covers 64 contiguous bytes per plane),
-// horizontal scans want many (GD=16: more waves, float4 per lane along W).  Running the four
-// directions on four streams was slower than back-to-back launches (0.97 vs 0.87 ms).
-// Fields are atomics: ganet_set_option() may race with launches on other threads (each launcher reads a field once).
+// One default path per operator (measured on MI355X, profiles/) plus its general fallback; the knobs exist so that tests can
+// reach the fallbacks and the forced modes.  Fields are atomics: ganet_set_option() may race with launches on other threads
+// (each launcher reads a field once).
 struct Options {
-  std::atomic<int> gd_v{4};
-  std::atomic<int> gd_h{16};
-  std::atomic<int> streams{0};
-  std::atomic<int> lga_wave{3};   // LGA forward / data-backward: 3 wave-autonomous, plane-pair packing (lga_apply_pp), 2 wave-autonomous + LDS-DMA ring, 1 wave-autonomous + register staging, 0 256-thread tiles
-  std::atomic<int> lga_mix{0};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 = off (not measured yet)
-  std::atomic<int> wide_col{0};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks); 0 = off (not measured yet)
+  std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
+  std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
+  std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
+  std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
   std::atomic<int> wide_scan{1};    // SGA scans with the whole wavefront on one scanline: 1 for inputs with few scanlines (and D > 272), 0 never, 2 whenever D > 48 (tests)
-  std::atomic<int> lga_bwd_streams{0};   // 1: filter gradient and data-backward of an LGA backward pass on two streams
-  std::atomic<int> lga_fg_wps{3};   // plane-pair filter gradient: register budget for 3 waves per SIMD (no LDS look-ahead) or 2 (two rows)
-  std::atomic<int> lga_vmcnt_safe{0};   // 1: the LDS-DMA kernels never count result stores when they wait for a staged plane (waits earlier than necessary)
-  std::atomic<int> lga_segs{0};   // depth segments per tile for those kernels (0 = automatic)
-  std::atomic<int> lga_split{1};  // automatic mode: unequal two-way depth split sized to the wave slots (LgaSeg::split_a)
-  std::atomic<int> rowwave{1};      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h)
-  std::atomic<int> colblock{1};     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h)
-  std::atomic<int> point_block{256};   // threads per block of the per-pixel gradient kernel
-  std::atomic<int> infer_fused{1};  // ganet_sga_forward_infer: running direction max inside the scans (no directional volumes)
-  std::atomic<int> merge4{1};       // merge + arg-max: four pixels per lane (16-byte requests)
-  std::atomic<int> block_v{128};
-  std::atomic<int> block_h{64};
+  std::atomic<int> rowwave{1};      // horizontal scans: one wavefront per row, LDS-staged (sga_row_kernels.h); 0 = segment kernels (the fallback)
+  std::atomic<int> colblock{1};     // vertical scans: 16-column blocks, LDS-staged (sga_col_kernels.h); 0 = segment kernels (the fallback)
 };
 Options g_opt;
 std::once_flag g_opt_once;
@@ -90,25 +76,13 @@ void load_env_options()
     const char *v = getenv(name);
     if (v && *v) dst = atoi(v);
   };
-  geti("GANET_SGA_GD_V", g_opt.gd_v);
-  geti("GANET_SGA_GD_H", g_opt.gd_h);
-  geti("GANET_SGA_STREAMS", g_opt.streams);
   geti("GANET_LGA_WAVE", g_opt.lga_wave);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
-  geti("GANET_LGA_VMCNT_SAFE", g_opt.lga_vmcnt_safe);
-  geti("GANET_LGA_FG_WPS", g_opt.lga_fg_wps);
-  geti("GANET_LGA_BWD_STREAMS", g_opt.lga_bwd_streams);
+  geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
-  geti("GANET_LGA_MIX", g_opt.lga_mix);
-  geti("GANET_LGA_SPLIT", g_opt.lga_split);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
   geti("GANET_SGA_COLBLOCK", g_opt.colblock);
-  geti("GANET_SGA_MERGE4", g_opt.merge4);
-  geti("GANET_SGA_INFER_FUSED", g_opt.infer_fused);
-  geti("GANET_SGA_POINT_BLOCK", g_opt.point_block);
-  geti("GANET_SGA_BLOCK_V", g_opt.block_v);
-  geti("GANET_SGA_BLOCK_H", g_opt.block_h);
 }
 const Options &opts()
 {
@@ -116,39 +90,11 @@ const Options &opts()
   return g_opt;
 }
 
-// ---- side streams: one per extra aggregation direction, per device ------------------
-struct SidePool {
-  bool ready = false;
-  hipStream_t s[3];
-  hipEvent_t fork, join[3];
-};
-SidePool g_pool[16];
-std::mutex g_pool_mu;
-
-int get_pool(SidePool **out)
-{
-  int dev = 0;
-  GA_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(GANET_E_RUNTIME, "device index %d out of range", dev);
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  SidePool &p = g_pool[dev];
-  if (!p.ready) {
-    for (int i = 0; i < 3; i++) {
-      GA_HIP(hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking));
-      GA_HIP(hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming));
-    }
-    GA_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
-    p.ready = true;
-  }
-  *out = &p;
-  return GANET_OK;
-}
-
 // ---- SGA kernel selection -----------------------------------------------------------
 // (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
 // GD = 64: the whole wavefront owns one scanline (D up to 1,088; 4x the waves of GD = 16 for inputs with few scanlines)
 #define GA_SGA_PAIRS(X) \
-  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) X(8, 5) X(8, 9) X(4, 5) X(4, 9) X(4, 17) \
+  X(16, 1) X(16, 2) X(16, 3) X(16, 5) X(16, 9) X(16, 13) X(16, 17) \
   X(64, 3) X(64, 5) X(64, 9) X(64, 17)
 
 constexpr int fwd_sb(int dpl) { return dpl <= 3 ? 8 : dpl <= 5 ? 4 : dpl <= 9 ? 2 : 1; }
@@ -166,7 +112,6 @@ bool pick_pair(int D, int want_gd, int *gd, int *dpl)
   }
   GA_SGA_PAIRS(X)
 #undef X
-  if (best_gd == 0 && want_gd != 16 && want_gd != 64) return pick_pair(D, 16, gd, dpl);
   if (best_gd == 0 && want_gd == 16) return pick_pair(D, 64, gd, dpl);      // D > 272: wave-wide scanlines
   if (best_gd == 0) return false;
   *gd = best_gd;
@@ -198,11 +143,9 @@ template <int GD, int DPL>
 int launch_scan_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir,
                     hipStream_t st)
 {
-  const Options &o = opts();
   ScanGeom geo = make_geom(S, D, H, W, dir, false);
   const bool rowvec = DPL <= 17 && dir >= 2 && (W % 4 == 0) && aligned16(x) && aligned16(g) && aligned16(A);
-  int block = dir < 2 ? o.block_v : o.block_h;
-  if (block < 64 || block > 256 || block % 64) block = 64;
+  const int block = dir < 2 ? 128 : 64;      // (measured defaults of round 1, profiles/r1_tune_sga.txt)
   const int lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
   if (rowvec) {
@@ -219,12 +162,10 @@ template <int GD, int DPL>
 int launch_scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout,
                      float *G, int S, int D, int H, int W, int dir, hipStream_t st)
 {
-  const Options &o = opts();
   ScanGeom geo = make_geom(S, D, H, W, dir, true);
   const bool rowvec = DPL <= 17 && dir >= 2 && (W % 4 == 0) && aligned16(g) && aligned16(gout) &&
                       aligned16(G) && (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
-  int block = dir < 2 ? o.block_v : o.block_h;
-  if (block < 64 || block > 256 || block % 64) block = 64;
+  const int block = dir < 2 ? 128 : 64;      // (measured defaults of round 1, profiles/r1_tune_sga.txt)
   const int lpb = block / GD;
   const int grid = (geo.total_lines + lpb - 1) / lpb;
   if (rowvec) {
@@ -322,11 +263,17 @@ int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W
 // For inputs with few column blocks (SURVEY 8d's stress shape [1,1,192,240,624]: 39 blocks) and many disparities: 16 waves
 // per block instead of 4, 3-5 disparities of serial work per lane instead of 12-13, and -- unlike the register-only wide
 // segment kernels -- the same 64-byte global pieces as the 16-lane column blocks.  D <= 192; up to 112 KB of LDS per block.
+int device_cus();
 constexpr size_t COL_WIDE_SMEM_MAX = 152 * 1024;
 int col_wide_dpl(int D) { return D <= 64 * 3 ? 3 : 0; }      // (5 disparities per lane spill at the 128 registers a 1,024-thread block leaves)
 bool col_wide_ok(int D, int W, int dir, size_t smem, int S)
 {
-  return opts().wide_col && dir < 2 && W % 4 == 0 && col_wide_dpl(D) > 0 && smem <= COL_WIDE_SMEM_MAX && S <= 65535;
+  const int mode = opts().wide_col;
+  if (!mode || dir >= 2 || W % 4 != 0 || col_wide_dpl(D) <= 0 || smem > COL_WIDE_SMEM_MAX || S > 65535) return false;
+  if (mode >= 2) return true;
+  // automatic: fewer 16-column blocks than half the compute units (the 16-lane blocks would leave most SIMDs idle, each with
+  // 12-13 disparities of serial work per lane) -- the literal stress shape [1,1,192,240,624] has 39
+  return D >= 96 && (i64)S * ((W + COL_NC - 1) / COL_NC) * 2 <= device_cus();
 }
 
 int col_fwd_wide(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
@@ -453,7 +400,7 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
   if (colblock_ok(D, W, dir, col_smem_fwd(D)) && aligned16(x) && aligned16(g) && aligned16(A) && N * C <= 65535)
     return col_fwd(x, g, A, N * C, D, H, W, dir, st);
   int gd, dpl;
-  if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
+  if (!pick_pair(D, 16, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (1088)", D);
 #define X(G, P) \
   if (gd == (G) && dpl == (P)) return launch_scan_fwd<G, P>(x, g, A, N * C, D, H, W, dir, st);
@@ -484,7 +431,7 @@ int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const flo
       (((uintptr_t)mask & 3) == 0) && N * C <= 65535)
     return col_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
   int gd, dpl;
-  if (!pick_pair(D, dir < 2 ? opts().gd_v : opts().gd_h, &gd, &dpl))
+  if (!pick_pair(D, 16, &gd, &dpl))
     return fail(GANET_E_UNSUPPORTED, "SGA: D=%d exceeds the compiled maximum (1088)", D);
 #define X(G_, P) \
   if (gd == (G_) && dpl == (P)) return launch_scan_bwdg<G_, P>(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
@@ -519,8 +466,7 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
               int accumulate, hipStream_t st)
 {
   const i64 npix = (i64)N * C * H * W;
-  int pb = opts().point_block;
-  if (pb != 64 && pb != 128 && pb != 256) pb = 256;
+  const int pb = 256;      // (64 / 128 measured equal)
   i64 gsz = (npix + pb - 1) / pb;
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
@@ -559,74 +505,34 @@ int device_cus()
 }
 
 // ---- LGA dispatch -------------------------------------------------------------------
-// depth segments per tile for the wave-autonomous LGA kernels.  Every work item re-gathers its pixels'
-// filter taps (75 loads per lane; for the data-backward they come from 25 neighbouring pixels) and
-// reads two extra halo planes, so items should be as long as balance allows: measured at 240x624x193
-// (2,400 tiles; sweep of GANET_LGA_SEGS) the forward is fastest with ~4.5 items per SIMD (2 segments),
-// the data-backward with ~2.3 (1 segment); more segments cost 1-3 % each.
-int lga_segments(int tiles, int D, bool transposed)
-{
-  int nseg = opts().lga_segs;
-  if (nseg <= 0) {
-    const int target = transposed ? 2560 : 4608;
-    nseg = (target + tiles - 1) / tiles;
-    const int cap = D / 32 > 1 ? D / 32 : 1;
-    if (nseg > cap) nseg = cap;
-  }
-  if (nseg > D) nseg = D;
-  if (nseg < 1) nseg = 1;
-  return nseg;
-}
-
+// Work items of the plane-pair forward / data-backward = tiles x depth segments.  Every item re-gathers its pixels' filter
+// taps (75 loads per lane; for the data-backward from 25 neighbouring pixels) and fills its ring, 0.038 ms of a 0.107 ms pass
+// (profiles/r2f_lga_pp_ablation.txt), so ONE segment per tile is best (profiles/r2e_ab_lga_plane_pairs_v2.txt) unless there are
+// too few tiles to fill the wave slots; segments start on even planes (32-bit byte offsets inside a plane pair).
 template <int R>
 int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H, int W,
                    bool transposed, hipStream_t st)
 {
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  if (opts().lga_wave && (opts().lga_wave == 3 || (W % 2 == 0 && ((uintptr_t)x & 7) == 0)) && (i64)H * W < (1ll << 30)) {
-    LgaSeg sg;
-    sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-    sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-    const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
-    sg.split_a = 0;
-    sg.safe_wait = opts().lga_vmcnt_safe ? 1 : 0;
-    sg.nseg = lga_segments((int)(tiles < (1 << 30) ? tiles : (1 << 30)), D, transposed);
-    sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
-    sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
-    if (opts().lga_segs <= 0 && opts().lga_split && (!transposed || opts().lga_split > 1)) {   // (measured: helps the forward by 4 %, not the data-backward)
-      // unequal two-way split (see LgaSeg): the long segment is what one wave slot gets if all slots share the work
+  if constexpr (R <= 2) {
+    if (opts().lga_wave && (i64)H * W < (1ll << 28)) {
+      LgaSeg sg;
+      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+      const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
       const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
-      const i64 la = (tiles * D + slots - 1) / slots;
-      if (opts().lga_split > 1) {               // (forced first-segment length: tests)
-        if (opts().lga_split < D && 2 * tiles < (1ll << 31)) { sg.split_a = opts().lga_split; sg.nseg = 2; }
-      } else if (tiles < slots && la >= (D + 1) / 2 && la <= D - 16 && 2 * tiles < (1ll << 31)) {
-        sg.split_a = (int)la;
-        sg.nseg = 2;
-      } else if (tiles < slots && la > D - 16) {
-        sg.nseg = 1; sg.seg_len = D;          // nearly one item per slot already
-      }
-    }
-    if (opts().lga_wave == 3 && (i64)H * W < (1ll << 28)) {
-      // plane-pair kernel: segments start on even planes (32-bit byte offsets inside a plane pair).  Measured at 240x624x193
-      // (profiles/r2e_ab_lga_plane_pairs_v2.txt): ONE segment is best for both the forward (0.099 ms) and the data-backward --
-      // every work item pays the weight gather and a pipeline fill (0.038 ms of a 0.107 ms pass in the ablation,
-      // profiles/r2f_lga_pp_ablation.txt) -- unless there are too few tiles to fill the chip
-      if (opts().lga_segs <= 0 && opts().lga_split <= 1) {
-        const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
-        sg.split_a = 0;
+      sg.nseg = opts().lga_segs;
+      if (sg.nseg <= 0) {
         sg.nseg = tiles * 2 > slots ? 1 : (int)((slots + tiles - 1) / tiles);
         if (sg.nseg > D / 16) sg.nseg = D / 16 > 1 ? D / 16 : 1;
-        sg.seg_len = (D + sg.nseg - 1) / sg.nseg;
       }
-      if (sg.split_a > 0) sg.split_a &= ~1;
-      if (sg.split_a <= 0) {
-        sg.split_a = 0;
-        sg.seg_len = (sg.seg_len + 1) & ~1;
-        sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
-      }
+      if (sg.nseg > D) sg.nseg = D;
+      sg.seg_len = ((D + sg.nseg - 1) / sg.nseg + 1) & ~1;
+      sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
+      static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
       if constexpr (R == 2) {
-        // mixed item list (GANET_LGA_MIX, see LgaSegMix): q whole tiles per SIMD + at most one segment of the remaining ones
+        // mixed item list (LgaSegMix): q whole tiles per SIMD + at most one segment of the remaining ones
         const int mixo = opts().lga_mix;
         const i64 S = mixo > 1 ? (i64)mixo : (i64)4 * device_cus();
         if (mixo && opts().lga_segs <= 0 && tiles < (1ll << 30) && tiles / S < LGA_WAVES_PER_SIMD && tiles % S != 0) {
@@ -642,33 +548,18 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
             const i64 items_mx = mx.n_whole + r * mx.nsub;
             if (transposed) GA_LAUNCH((lga_apply_pp_mix<R, true>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
             else GA_LAUNCH((lga_apply_pp_mix<R, false>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
-            static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;
             if (trace) fprintf(stderr, "[ganet] lga_apply_pp_mix T=%d whole=%d + %lld x %d segments of %d planes\n", (int)transposed, mx.n_whole, (long long)r, mx.nsub, mx.sub_len);
             return check_launch("lga apply (plane pairs, mixed item list)");
           }
         }
       }
       const i64 items_pp = tiles * sg.nseg;
-      if constexpr (R <= 2) if (items_pp < (1ll << 31)) {
+      if (items_pp < (1ll << 31)) {
         if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
         else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
-        if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d split=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg, sg.split_a);
+        if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg);
         return check_launch("lga apply (plane pairs)");
       }
-    }
-    const i64 items = tiles * sg.nseg;
-    if constexpr (LgaDCfg<R>::OK) {
-      if (items < (1ll << 31) && opts().lga_wave >= 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0) {
-        if (transposed) GA_LAUNCH((lga_apply_dma<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-        else GA_LAUNCH((lga_apply_dma<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-        return check_launch("lga apply (dma)");
-      }
-    }
-    if (items < (1ll << 31) && W % 2 == 0 && ((uintptr_t)x & 7) == 0) {
-      if (transposed) GA_LAUNCH((lga_apply_wave<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-      else GA_LAUNCH((lga_apply_wave<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-      return check_launch("lga apply (wave)");
     }
   }
   const dim3 grid((W + LGA_TW - 1) / LGA_TW, (H + LGA_TH - 1) / LGA_TH, B);
@@ -688,7 +579,7 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   LgaSeg sg;
   sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
   sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-  sg.nseg = 1; sg.seg_len = (D + 1) & ~1; sg.split_a = 0; sg.safe_wait = 0;
+  sg.nseg = 1; sg.seg_len = (D + 1) & ~1;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: too many tiles");
   if (x_paired) {
@@ -711,17 +602,11 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   LgaSeg sg;
   sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
   sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-  sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
+  sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  const bool w2 = opts().lga_fg_wps == 2;
-  if (x_paired) {
-    if (w2) GA_LAUNCH((lga_filter_grad_pp_xp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-    else GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  } else {
-    if (w2) GA_LAUNCH((lga_filter_grad_pp_gyp<2, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-    else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  }
+  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
 }
 
@@ -737,7 +622,7 @@ int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snor
       LgaSeg sg;
       sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
       sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = (D + 1) & ~1; sg.split_a = 0; sg.safe_wait = 0;
+      sg.nseg = 1; sg.seg_len = (D + 1) & ~1;
       const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
       if (items < (1ll << 31)) {
         GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
@@ -756,29 +641,15 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   if constexpr (R <= 2) {
-    if (opts().lga_wave == 3 && (i64)H * W < (1ll << 28)) {
+    if (opts().lga_wave && (i64)H * W < (1ll << 28)) {
       LgaSeg sg;
       sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
       sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
+      sg.nseg = 1; sg.seg_len = D;
       const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
       if (items < (1ll << 31)) {
-        if (opts().lga_fg_wps == 2) GA_LAUNCH((lga_filter_grad_pp<R, 2, 2>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-        else GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         return check_launch("lga filter grad (plane pairs)");
-      }
-    }
-  }
-  if constexpr (LgaDCfg<R>::OK) {
-    if (opts().lga_wave >= 2 && W % 4 == 0 && ((uintptr_t)x & 15) == 0 && (i64)H * W < (1ll << 31)) {
-      LgaSeg sg;
-      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = D; sg.split_a = 0; sg.safe_wait = 0;
-      const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
-      if (items < (1ll << 31)) {
-        GA_LAUNCH((lga_filter_grad_dma<R>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-        return check_launch("lga filter grad (dma)");
       }
     }
   }
@@ -841,27 +712,13 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 {
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
-  if (!strcmp(name, "GANET_SGA_GD") || !strcmp(name, "GANET_SGA_GD_V") || !strcmp(name, "GANET_SGA_GD_H")) {
-    if (value != 4 && value != 8 && value != 16) return fail(GANET_E_INVALID, "%s must be 4, 8 or 16", name);
-    if (strcmp(name, "GANET_SGA_GD_H")) g_opt.gd_v = value;
-    if (strcmp(name, "GANET_SGA_GD_V")) g_opt.gd_h = value;
-  } else if (!strcmp(name, "GANET_SGA_STREAMS")) g_opt.streams = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : (value > 3 ? 3 : value);
-  else if (!strcmp(name, "GANET_LGA_VMCNT_SAFE")) g_opt.lga_vmcnt_safe = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_FG_WPS")) g_opt.lga_fg_wps = value == 2 ? 2 : 3;
-  else if (!strcmp(name, "GANET_LGA_BWD_STREAMS")) g_opt.lga_bwd_streams = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
-  else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value ? 1 : 0;
+  if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_LGA_SPLIT")) g_opt.lga_split = value > 0 ? value : 0;   // 0 off, 1 automatic, n > 1: first segment of n planes
+  else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_MERGE4")) g_opt.merge4 = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_INFER_FUSED")) g_opt.infer_fused = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_POINT_BLOCK")) g_opt.point_block = value;
-  else if (!strcmp(name, "GANET_SGA_BLOCK_V")) g_opt.block_v = value;
-  else if (!strcmp(name, "GANET_SGA_BLOCK_H")) g_opt.block_h = value;
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
   else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;
@@ -891,22 +748,10 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
-  if (opts().streams) {
-    SidePool *p;
-    GA_TRY(get_pool(&p));
-    GA_HIP(hipEventRecord(p->fork, st));
-    GA_TRY(scan_fwd(x, gs[0], A_ws, N, C, D, H, W, 0, st));
-    for (int d = 1; d < 4; d++) {
-      GA_HIP(hipStreamWaitEvent(p->s[d - 1], p->fork, 0));
-      GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, p->s[d - 1]));
-      GA_HIP(hipEventRecord(p->join[d - 1], p->s[d - 1]));
-      GA_HIP(hipStreamWaitEvent(st, p->join[d - 1], 0));
-    }
-  } else {
-    for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
-  }
+  // (the four scans on four streams were measured twice and dropped: 0.596 vs 0.606 ms)
+  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   const i64 HWl = (i64)H * W;
-  if (opts().merge4 && HWl % 4 == 0 && aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) &&
+  if (HWl % 4 == 0 && aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) &&
       (((uintptr_t)kp & 7) == 0) && npix / 4 / 64 + 1 < (1ll << 31)) {
     GA_LAUNCH(sga_merge_px4, dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
               A_ws + 3 * n, out, mask, kp, D, HWl, npix);
@@ -922,7 +767,7 @@ bool infer_fused_ok(const float *x, const float *g0, const float *g1, const floa
                     int N, int C, int D, int W)
 {
   const bool all_al = aligned16(x) && aligned16(out) && aligned16(g0) && aligned16(g1) && aligned16(g2) && aligned16(g3);
-  return opts().infer_fused && all_al && N * C <= 65535 && rowwave_ok(D, W, 2, row_smem_fwd(D)) &&
+  return all_al && N * C <= 65535 && rowwave_ok(D, W, 2, row_smem_fwd(D)) &&
          colblock_ok(D, W, 0, col_smem_fwd(D));
 }
 }  // namespace
@@ -1134,24 +979,11 @@ GA_EXPORT int ganet_lga_backward(const float *x, const float *f, const float *gy
   const int acc = accumulate_gf ? 1 : 0;
   // filter gradient first: it is the only consumer of x, so gx may alias x afterwards
   // (the reference's chained LGA2/LGA3 backward relies on that, functions/GANet.py:197).
-  // GANET_LGA_BWD_STREAMS=1: the two kernels of the pass are independent unless gx aliases x; each fills only ~3/4 of the
-  // chip's wave slots (2,400 single-wave workgroups on 3,072 slots at 240x624), so they may share it on two streams.
-  hipStream_t st_gf = st;
-  SidePool *pool = nullptr;
-  if (opts().lga_bwd_streams && gx != x) {
-    GA_TRY(get_pool(&pool));
-    GA_HIP(hipEventRecord(pool->fork, st));
-    GA_HIP(hipStreamWaitEvent(pool->s[0], pool->fork, 0));
-    st_gf = pool->s[0];
-  }
+  // (the two kernels of a pass on two streams: measured slower, 0.215 -> 0.238 ms, profiles/r2m_*)
   int rc;
-  if (radius == 1) { rc = launch_lga_gf<1>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<1>(gy, f, gx, B, D, H, W, true, st); }
-  else if (radius == 2) { rc = launch_lga_gf<2>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<2>(gy, f, gx, B, D, H, W, true, st); }
-  else { rc = launch_lga_gf<3>(x, gy, gf, B, D, H, W, acc, st_gf); if (rc == GANET_OK) rc = launch_lga_fwd<3>(gy, f, gx, B, D, H, W, true, st); }
-  if (pool) {
-    GA_HIP(hipEventRecord(pool->join[0], pool->s[0]));
-    GA_HIP(hipStreamWaitEvent(st, pool->join[0], 0));
-  }
+  if (radius == 1) { rc = launch_lga_gf<1>(x, gy, gf, B, D, H, W, acc, st); if (rc == GANET_OK) rc = launch_lga_fwd<1>(gy, f, gx, B, D, H, W, true, st); }
+  else if (radius == 2) { rc = launch_lga_gf<2>(x, gy, gf, B, D, H, W, acc, st); if (rc == GANET_OK) rc = launch_lga_fwd<2>(gy, f, gx, B, D, H, W, true, st); }
+  else { rc = launch_lga_gf<3>(x, gy, gf, B, D, H, W, acc, st); if (rc == GANET_OK) rc = launch_lga_fwd<3>(gy, f, gx, B, D, H, W, true, st); }
   return rc;
 }
 

@@ -321,311 +321,43 @@ lga_apply(const float *__restrict__ x, const float *__restrict__ f, float *__res
   }
 }
 
-// ---- wave-autonomous forward / data-backward -----------------------------------------
-// Same arithmetic as lga_apply, different decomposition.  What the counters said about the
-// 256-thread version (profiles/r1i_pmc_summary.txt, lga_apply<2, false>): 2,400 waves on 1,024 SIMDs leave every SIMD
-// with 2 or 3 waves and the kernel lasts as long as the 3-wave ones; the four waves of a block sit
-// on four differently loaded SIMDs and meet at a barrier every chunk, so all of them run at the
-// pace of the slowest (37 % of wave time parked).  Here one WAVE owns a 32 x 2 pixel tile and a
-// SEGMENT of the disparity range, stages its own halo rows (6 x 36 floats per plane, 8-byte
-// loads) into a private LDS ring and never meets a barrier: LDS operations of one wave execute
-// in order, which is all the hand-off needs.  Work items = tiles x segments (7,200 at 240x624x193)
-// are an order of magnitude more numerous than SIMDs, so the dispatcher evens the load out.
-#ifndef LGA_ABLATE
-#define LGA_ABLATE 0          // development only: bit 0 no staging loads, 1 no y stores, 2 no LDS reads, 3 no LDS writes
-#endif
+// ---- wave-autonomous kernels: common definitions -----------------------------------------------------------------
+// What the counters said about the 256-thread version (profiles/r1i_pmc_summary.txt, lga_apply<2, false>): 2,400 waves on
+// 1,024 SIMDs leave every SIMD with 2 or 3 waves and the kernel lasts as long as the 3-wave ones; the four waves of a block
+// sit on four differently loaded SIMDs and meet at a barrier every chunk, so all of them run at the pace of the slowest
+// (37 % of wave time parked).  In the plane-pair kernels below one WAVE owns a 32 x 2 pixel tile (and a SEGMENT of the
+// disparity range), stages its own halo rows into a private LDS ring by LDS-DMA and never meets a barrier.
+// (Two earlier families of the same decomposition -- register-staged, and LDS-DMA with column-packed FMAs -- were the
+// defaults of round 1 and were removed in round 3; their measurements are in DESIGN.md section 7 and profiles/r1*.)
 constexpr int LGAW_TH = 2;       // pixel rows per wave (lanes = LGA_TW x LGAW_TH = 64)
-#ifndef LGAW_PB
-#define LGAW_PB 3                // planes per private stage
-#endif
 #ifndef LGAW_LA
-#define LGAW_LA 2                // row steps of LDS lookahead (LGAW_LA + 1 must divide LGAW_PB * (2R+1))
+#define LGAW_LA 2                // row steps of LDS lookahead
 #endif
-template <int R> struct LgaWCfg {
-  static constexpr int TW2 = LgaCfg<R>::TW2;
-  static constexpr int HP = TW2 / 2;                       // float2 per tile row
-  static constexpr int TH2 = LGAW_TH + 2 * R;
-  static constexpr int PLANE = TW2 * TH2;
-  static constexpr int PAIRS = PLANE / 2;
-  static constexpr int NLP = (PAIRS + 63) / 64;            // 8-byte loads per lane per plane
-  static constexpr int PSTRIDE = NLP * 128;                // plane stride in LDS: every lane owns NLP cells
-  static constexpr int STAGE = PSTRIDE * LGAW_PB;
-};
 
-
-// Work items of the wave-autonomous kernels = tiles x depth segments.  Two forms:
-//  * split_a == 0: nseg equal segments of seg_len planes, segment fastest in the item order;
-//  * split_a  > 0: two UNEQUAL segments per tile, [0, split_a) and [split_a, D), and all the long ones come first in
-//    the item order.  With fewer tiles than wave slots (3 per SIMD) equal halves mean two dispatch rounds of which
-//    the second is half empty (4,800 items on 3,072 slots at 240x624: 2 x 98 plane-times); with split_a ~ tiles*D/slots
-//    the long items take one slot each for the whole kernel and the short ones share the remaining slots, a few each:
-//    every slot is busy for ~tiles*D/slots plane-times (151 at 240x624).  Measured: forward pass 0.108 -> 0.103 ms
-//    (the slot model overstates it: a SIMD's waves share one VALU); no gain for the data-backward, which keeps one
-//    segment.
+// Work items of the plane-pair forward / data-backward = tiles x nseg equal depth segments of seg_len planes, segment fastest
+// in the item order.
 struct LgaSeg {
   int nseg, seg_len, tiles_x, tiles_y;
-  int split_a;
-  int safe_wait;      // lga_apply_dma: never count y stores when waiting for a staged plane (GANET_LGA_VMCNT_SAFE)
 };
 
 // item -> (tile bx, by, batch b, depth range); each XCD (block id % 8) gets a contiguous band of tiles
 GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, int &d_lo, int &d_hi)
 {
-  int item, seg;
-  if (sg.split_a > 0) {
-    const int ntile = (int)(gridDim.x >> 1);
-    seg = (int)blockIdx.x >= ntile ? 1 : 0;
-    item = xcd_remap((int)blockIdx.x - seg * ntile, ntile);
-    d_lo = seg ? sg.split_a : 0;
-    d_hi = seg ? D : sg.split_a;
-  } else {
-    item = xcd_remap(blockIdx.x, gridDim.x);        // segment fastest: the segments of a tile read the same filter lines
-    seg = item % sg.nseg; item /= sg.nseg;
-    d_lo = seg * sg.seg_len;
-    d_hi = d_lo + sg.seg_len < D ? d_lo + sg.seg_len : D;
-  }
+  int item = xcd_remap(blockIdx.x, gridDim.x);        // segment fastest: the segments of a tile read the same filter lines
+  const int seg = item % sg.nseg;
+  item /= sg.nseg;
+  d_lo = seg * sg.seg_len;
+  d_hi = d_lo + sg.seg_len < D ? d_lo + sg.seg_len : D;
   bx = item % sg.tiles_x; item /= sg.tiles_x;
   by = item % sg.tiles_y;
   b = item / sg.tiles_y;
 }
 
-template <int R, bool TRANSPOSED>
-__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
-lga_apply_wave(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
-               LgaGeom geo, LgaSeg sg)
-{
-  typedef LgaCfg<R> C;
-  typedef LgaWCfg<R> WC;
-  __shared__ __attribute__((aligned(16))) float tile[2][WC::STAGE];
-  const int lane = threadIdx.x;                       // blockDim.x == 64
-  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int bx, by, b, d_lo, d_hi;
-  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);
-  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
-  const int i = ty0 + ty, j = tx0 + tx;
-  const bool inb = i < geo.H && j < geo.W;
-  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
-  const float *xb = x + (i64)b * geo.D * geo.HW;
-  const float *fb = f + (i64)b * 3 * C::K * geo.HW;
-  float *yb = y + (i64)b * geo.D * geo.HW;
-  const i64 pix = (i64)ic * geo.W + jc;
-  const int wcol = tx + C::RE - R;
-  const int par = wcol & 1;
-  const int rcol = wcol - par;
 
-  // output planes [d_lo, d_hi) need input planes [d_lo - 1, d_hi]
-  if (d_lo >= geo.D) return;
-  const int v_lo = d_lo > 0 ? d_lo - 1 : 0;
-  const int v_hi = d_hi < geo.D ? d_hi : geo.D - 1;    // inclusive
-
-  f2 wab[C::WS][C::NK];
-  f2 wc[C::WS][C::NP];
-  float cmid = 0.f, sin_m = 0.f, sin_p = 0.f;
-  const bool interior = ty0 >= R && ty0 + LGAW_TH + R <= geo.H && tx0 >= R && tx0 + LGA_TW + R <= geo.W;
-  if (interior)
-    lga_gather_weights<R, TRANSPOSED, false>(fb, geo, ic, jc, par, wab, wc, cmid, sin_m, sin_p);
-  else
-    lga_gather_weights<R, TRANSPOSED, true>(fb, geo, ic, jc, par, wab, wc, cmid, sin_m, sin_p);
-
-  // private staging: which float2 of the tile (+halo) this lane copies; the same for every plane.
-  // Straight-line on purpose: every lane loads from an always-valid address, the value is ANDed
-  // with an all-ones / zero mask and written to a cell the lane owns (the plane stride is padded
-  // to 64 * NLP cells).  A "valid ? load : 0" select is turned back into a branch per load by the
-  // compiler, and the zero-initialised destination registers then cost an s_waitcnt vmcnt(0) in
-  // front of every load group -- four serialised HBM round trips per chunk (61 % of wave time
-  // parked in the first version of this kernel).
-  int off[WC::NLP];
-  unsigned msk[WC::NLP];
-#pragma unroll
-  for (int h = 0; h < WC::NLP; h++) {
-    const int e2 = h * 64 + lane;
-    off[h] = 0;
-    msk[h] = 0u;
-    if (e2 < WC::PAIRS) {
-      const int r = e2 / WC::HP, c2 = e2 - r * WC::HP;
-      const int i2 = ty0 + r - R, j2 = tx0 + 2 * c2 - C::RE;      // j2 even, W even: a pair is in or out as a whole
-      if (i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W) { off[h] = i2 * geo.W + j2; msk[h] = ~0u; }
-    }
-  }
-  // fetch / commit are unconditional (planes past the segment are clamped to its last plane and
-  // land in cells nobody reads): with a condition around them the compiler has to assume a load
-  // may still be pending on the loop back edge and guards every reuse of its registers with
-  // s_waitcnt vmcnt(0), which serialises the prefetch.
-  uint2 regs[LGAW_PB][WC::NLP];
-  auto fetch = [&](int c) {
-#pragma unroll
-    for (int pl = 0; pl < LGAW_PB; pl++) {
-      int d = v_lo + c * LGAW_PB + pl;
-      d = d < v_hi ? d : v_hi;
-      const float *pb = xb + (i64)d * geo.HW;
-#pragma unroll
-      for (int h = 0; h < WC::NLP; h++) regs[pl][h] = *reinterpret_cast<const uint2 *>(pb + off[h]);
-    }
-  };
-  auto commit = [&](int c) {
-    float *buf = tile[c & 1];
-#pragma unroll
-    for (int pl = 0; pl < LGAW_PB; pl++) {
-#pragma unroll
-      for (int h = 0; h < WC::NLP; h++) {
-        uint2 u = regs[pl][h];
-        u.x &= msk[h];
-        u.y &= msk[h];
-        *reinterpret_cast<uint2 *>(buf + pl * WC::PSTRIDE + 2 * (h * 64 + lane)) = u;
-      }
-    }
-  };
-
-  const int nchunks = (v_hi - v_lo + LGAW_PB) / LGAW_PB;
-  fetch(0);
-  commit(0);
-  GA_WAVE_SYNC();
-
-  // The window rows of a chunk form one stream of LGAW_PB * WS "row steps".  The LDS reads of
-  // step s + LA are issued before step s is computed, across plane boundaries and -- for the last
-  // LA steps -- into the next chunk's buffer, which is why that buffer is committed before the
-  // chunk's last plane starts.  Every plane is computed unconditionally (past the segment end the
-  // data is a clamped copy and the result is dropped), so a chunk is straight-line code.
-  constexpr int LA = LGAW_LA;                             // row steps of LDS lookahead
-  constexpr int NSTEP = LGAW_PB * C::WS;
-  static_assert(C::WS > LA, "lookahead must stay within one plane of the next chunk");
-  static_assert(NSTEP % (LA + 1) == 0, "the row ring must close on a chunk boundary");
-  const lds_cptr lbase = GA_LDS_CPTR(&tile[0][0]) + ty * WC::TW2 + rcol;
-  f2 vrow[LA + 1][C::NP];
-#pragma unroll
-  for (int s0 = 0; s0 < LA; s0++) {
-#pragma unroll
-    for (int q = 0; q < C::NP; q++) vrow[s0][q] = lds_read_b64(lbase + s0 * WC::TW2 + 2 * q);
-  }
-
-  float acc_a = 0.f, acc_b = 0.f;
-  float xc_prev = 0.f;
-  float *yp = yb + (i64)d_lo * geo.HW + pix;     // next output plane of the own pixel
-  for (int c = 0; c < nchunks; c++) {
-#if !(LGA_ABLATE & 1)
-    fetch(c + 1);
-#endif
-    const lds_cptr cur = lbase + (c & 1) * WC::STAGE, nxt = lbase + ((c + 1) & 1) * WC::STAGE;
-    f2 s_x[2], s_y[2], s_p[2];
-    float xc = 0.f;
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-      const int pl = st / C::WS, a = st % C::WS;
-      if (st == (LGAW_PB - 1) * C::WS) {
-        GA_WAVE_SYNC();        // (all lanes are past their reads of the buffer about to be overwritten)
-#if !(LGA_ABLATE & 8)
-        commit(c + 1);
-#endif
-        GA_WAVE_SYNC();
-      }
-      {
-        const int t = st + LA;
-        const lds_cptr src = t < NSTEP ? cur + (t / C::WS) * WC::PSTRIDE + (t % C::WS) * WC::TW2
-                                       : nxt + (t - NSTEP) * WC::TW2;
-#pragma unroll
-        for (int q = 0; q < C::NP; q++) {
-#if LGA_ABLATE & 4
-          if (c == 0)
-#endif
-          vrow[t % (LA + 1)][q] = lds_read_b64(src + 2 * q);
-        }
-      }
-      GA_SCHED_FENCE();
-      if (a == 0) {
-        s_x[0] = s_x[1] = s_y[0] = s_y[1] = s_p[0] = s_p[1] = mk2(0.f, 0.f);
-      }
-      // six accumulator chains in a fixed rotation (see lga_apply)
-#pragma unroll
-      for (int q = 0; q < C::NP; q++) {
-        const f2 vv = vrow[st % (LA + 1)][q];
-        const int ch = (a * C::NP + q) & 1;
-        s_x[ch] = fma2(mk2(vv.x, vv.x), wab[a][2 * q], s_x[ch]);
-        s_y[ch] = fma2(mk2(vv.y, vv.y), wab[a][2 * q + 1], s_y[ch]);
-        s_p[ch] = fma2(vv, wc[a][q], s_p[ch]);
-        GA_SCHED_FENCE();
-        if (a == R && 2 * q <= R && R <= 2 * q + 1) {
-          const float c0 = (R & 1) ? vv.y : vv.x;
-          xc = par ? xc : c0;
-        }
-        if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
-          const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
-          xc = par ? c1 : xc;
-        }
-      }
-      if (a == C::WS - 1) {
-        const int d = v_lo + c * LGAW_PB + pl;
-        GA_KEEP_F2(s_x[0]); GA_KEEP_F2(s_x[1]); GA_KEEP_F2(s_y[0]); GA_KEEP_F2(s_y[1]); GA_KEEP_F2(s_p[0]); GA_KEEP_F2(s_p[1]);
-        const f2 t_x = add2(s_x[0], s_x[1]), t_y = add2(s_y[0], s_y[1]), t_p = add2(s_p[0], s_p[1]);
-        const float zm = t_x.x + t_y.x;                       // depth slab -1 -> y[d+1]
-        const float z0 = t_x.y + t_y.y;                       // depth slab  0 -> y[d]
-        const float zp = t_p.x + t_p.y;                       // depth slab +1 -> y[d-1]
-        const bool live = d <= v_hi;                          // uniform
-        if (live && d - 1 >= d_lo) {
-          const int dy = d - 1;
-          float cc = cmid;
-          if (dy == 0) cc += sin_m;
-          const float r = fmaf(xc_prev, cc, acc_a + zp);
-#if LGA_ABLATE & 2
-          if (inb && r == 123.456f) *yp = r;
-#else
-          if (inb) *yp = r;
-#endif
-          yp += geo.HW;
-        }
-        acc_a = live ? acc_b + z0 : acc_a;
-        acc_b = live ? zm : acc_b;
-        xc_prev = live ? xc : xc_prev;
-      }
-    }
-  }
-  if (d_hi == geo.D) {
-    const int dy = geo.D - 1;
-    float cc = cmid + sin_p;
-    if (dy == 0) cc += sin_m;
-    const float r = fmaf(xc_prev, cc, acc_a);
-    if (inb) *yp = r;
-  }
-}
-
-// ---- wave-autonomous forward / data-backward, LDS-DMA staging -------------------------
-// The register-staged wave kernel above still loses ~25 % of its time waiting for the staging
-// loads (ablation of this family: profiles/r1q_lga_ablation.txt): one chunk of look-ahead is all its registers
-// can hold.  Here the halo'd plane (6 rows x 40 floats = 60 16-byte groups at R = 2) is copied
-// global -> LDS by ONE global_load_lds_dwordx4 per plane, into a ring of LGAD_NR plane slots
-// private to the wave, LGAD_NR - 1 planes ahead of the arithmetic: no staging registers, no
-// ds_write, no masks (lanes whose group lies outside the image are switched off and their ring
-// cells stay zero from the initial clear).  hipcc does not count an asm LDS-DMA, so the waits
-// are explicit: after DMA(p + P) is issued, at least P - 1 vector-memory operations follow
-// DMA(p + 1), hence s_waitcnt vmcnt(P - 1) retires it (in-order counter; the y stores only make
-// the wait earlier than necessary).
-#ifndef LGAD_NR
-#define LGAD_NR 8                // ring slots per wave (960 B each at R = 2); 6 / 8 / 12 measured: 8 is 2 % ahead of 12 on the forward
-#endif
-template <int R> struct LgaDCfg {
-  static constexpr int HALO = 4;                           // column halo rounded up to a 16-byte group
-  static constexpr int TW2 = LGA_TW + 2 * HALO;
-  static constexpr int G = TW2 / 4;                        // 16-byte groups per tile row
-  static constexpr int TH2 = LGAW_TH + 2 * R;
-  static constexpr int NG = G * TH2;                       // groups per plane = lanes used by one DMA
-  static constexpr int PLANE = TW2 * TH2;                  // floats
-  static constexpr bool OK = NG <= 64;
-};
-
-// one 16-byte global -> LDS copy per active lane: lane l's bytes land at slot + 16 * l
-GA_DEV void lga_dma16(const float *gsrc, float *slot, int lane)
-{
-#if defined(GA_HIPSIM)
-  hipsim::dma_issue(slot + 4 * lane, gsrc, 4);
-#else
-  (void)lane;
-  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
-}
-// GA_DMA_MASKED(n): this lane sits out n copy instructions its wave issues (the wave's counter counts them all the same);
-// nothing on the GPU, book-keeping for the emulator's late-landing copy model (tests/hipsim/hipsim.h)
+// Emulator hooks of the LDS-DMA kernels.  hipcc does not count an asm global -> LDS copy, so their waits are explicit
+// (GA_VMCNT) and derived from the fixed issue order; GA_DMA_MASKED(n): this lane sits out n copy instructions its wave
+// issues (the wave's counter counts them all the same) -- nothing on the GPU, book-keeping for the emulator's late-landing
+// copy model (tests/hipsim/hipsim.h)
 #if defined(GA_HIPSIM)
 #define GA_VMCNT(n) hipsim::vmcnt(n)
 #define GA_LGKMCNT0() ((void)0)
@@ -635,190 +367,6 @@ GA_DEV void lga_dma16(const float *gsrc, float *slot, int lane)
 #define GA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define GA_DMA_MASKED(n) ((void)0)
 #endif
-
-template <int R, bool TRANSPOSED>
-__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
-lga_apply_dma(const float *__restrict__ x, const float *__restrict__ f, float *__restrict__ y,
-              LgaGeom geo, LgaSeg sg)
-{
-  typedef LgaCfg<R> C;
-  typedef LgaDCfg<R> DC;
-  static_assert(DC::OK, "one DMA instruction must cover a plane");
-  constexpr int NR = LGAD_NR, P = NR - 1;
-  __shared__ __attribute__((aligned(16))) float ring[NR * DC::PLANE];
-  const int lane = threadIdx.x;                       // blockDim.x == 64
-  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int bx, by, b, d_lo, d_hi;
-  lga_decode_item(sg, geo.D, bx, by, b, d_lo, d_hi);
-  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
-  const int i = ty0 + ty, j = tx0 + tx;
-  const bool inb = i < geo.H && j < geo.W;
-  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
-  const float *xb = x + (i64)b * geo.D * geo.HW;
-  const float *fb = f + (i64)b * 3 * C::K * geo.HW;
-  float *yb = y + (i64)b * geo.D * geo.HW;
-  const i64 pix = (i64)ic * geo.W + jc;
-  const int wcol = tx + DC::HALO - R;
-  const int par = wcol & 1;
-  const int rcol = wcol - par;
-
-  if (d_lo >= geo.D) return;
-  const int v_lo = d_lo > 0 ? d_lo - 1 : 0;
-  const int v_hi = d_hi < geo.D ? d_hi : geo.D - 1;    // inclusive
-
-  // clear the ring (cells of out-of-image groups are never written again), then start the DMA
-  // pipeline before the filter taps are gathered so that both latencies overlap
-#pragma unroll
-  for (int k = 0; k < (NR * DC::PLANE / 4 + 63) / 64; k++) {
-    const int e = k * 64 + lane;
-    if (e < NR * DC::PLANE / 4) *reinterpret_cast<f4 *>(ring + 4 * e) = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  GA_LGKMCNT0();
-  GA_WAVE_SYNC();
-  bool dma_on = false;
-  const float *gsrc = xb;
-  if (lane < DC::NG) {
-    const int r = lane / DC::G, c4 = lane - r * DC::G;
-    const int i2 = ty0 + r - R, j2 = tx0 - DC::HALO + 4 * c4;      // W % 4 == 0: a group is in or out as a whole
-    if (i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W) {
-      dma_on = true;
-      gsrc = xb + (i64)i2 * geo.W + j2;
-    }
-  }
-  // planes are requested in order k = 0, 1, 2, ... (relative to v_lo; past the segment end the last
-  // plane is requested again so that the operation count per step stays fixed)
-  const int nvis = v_hi - v_lo + 1;
-  gsrc += (i64)v_lo * geo.HW;
-  int dma_slot = 0;
-  auto dma = [&](int k) {
-    if (dma_on) lga_dma16(gsrc, ring + dma_slot * DC::PLANE, lane);
-    else GA_DMA_MASKED(1);
-    gsrc += k + 1 < nvis ? geo.HW : 0;
-    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-  };
-  for (int k = 0; k < P; k++) dma(k);
-
-  f2 wab[C::WS][C::NK];
-  f2 wc[C::WS][C::NP];
-  float cmid = 0.f, sin_m = 0.f, sin_p = 0.f;
-  const bool interior = ty0 >= R && ty0 + LGAW_TH + R <= geo.H && tx0 >= R && tx0 + LGA_TW + R <= geo.W;
-  if (interior)
-    lga_gather_weights<R, TRANSPOSED, false>(fb, geo, ic, jc, par, wab, wc, cmid, sin_m, sin_p);
-  else
-    lga_gather_weights<R, TRANSPOSED, true>(fb, geo, ic, jc, par, wab, wc, cmid, sin_m, sin_p);
-
-  // row stream with LA steps of LDS look-ahead, unrolled over U planes so that the row ring closes
-  constexpr int LA = LGAW_LA, U = LA + 1, NSTEP = U * C::WS;
-  static_assert(C::WS > LA, "look-ahead must stay within the next plane");
-  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + ty * DC::TW2 + rcol;
-  f2 vrow[LA + 1][C::NP];
-  GA_VMCNT(P - 1);                                         // plane 0 has landed
-  GA_WAVE_SYNC();
-#pragma unroll
-  for (int s0 = 0; s0 < LA; s0++) {
-#pragma unroll
-    for (int q = 0; q < C::NP; q++) vrow[s0][q] = lds_read_b64(lbase + s0 * DC::TW2 + 2 * q);
-  }
-
-  float acc_a = 0.f, acc_b = 0.f;
-  float xc_prev = 0.f;
-  float *yp = yb + (i64)d_lo * geo.HW + pix;     // next output plane of the own pixel
-  int slot_c = 0;                                // ring slot of the plane being computed
-  for (int k0 = 0; k0 < nvis; k0 += U) {
-    f2 s_x[2], s_y[2], s_p[2];
-    float xc = 0.f;
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-      const int u = st / C::WS, a = st % C::WS;
-      const int k = k0 + u;
-      if (a == 0) {
-        // the slot this overwrites held plane k - 1, whose rows have all been consumed
-#if !(LGA_ABLATE & 1)
-        dma(k + P);
-#endif
-      }
-      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
-      const lds_cptr cur = lbase + slot_c * DC::PLANE, nxt = lbase + slot_n * DC::PLANE;
-      if (a == C::WS - LA) {
-        // plane k + 1 must have landed.  After its DMA came P - 1 further DMAs and, once the march is
-        // under way, the P - 1 y stores of steps k + 1 - P .. k - 1 (every step from the third on
-        // issues exactly one: some lane of a tile is always inside the image)
-        int kk = k;
-        GA_OPAQUE_S(kk);                                   // (keeps the compiler from splitting the plane loop by range)
-        if (!sg.safe_wait && kk >= P + 1 && kk < nvis) GA_VMCNT(2 * (P - 1));
-        else GA_VMCNT(P - 1);                              // (always sufficient: the stores only make it earlier than needed)
-        GA_WAVE_SYNC();
-      }
-      {
-        const int t = a + LA;
-        const lds_cptr src = t < C::WS ? cur + t * DC::TW2 : nxt + (t - C::WS) * DC::TW2;
-#pragma unroll
-        for (int q = 0; q < C::NP; q++) {
-#if LGA_ABLATE & 4
-          GA_KEEP_F2(vrow[(st + LA) % (LA + 1)][q]);      // (ablation: no LDS read, value still opaque)
-#else
-          vrow[(st + LA) % (LA + 1)][q] = lds_read_b64(src + 2 * q);
-#endif
-        }
-      }
-      GA_SCHED_FENCE();
-      if (a == 0) {
-        s_x[0] = s_x[1] = s_y[0] = s_y[1] = s_p[0] = s_p[1] = mk2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int q = 0; q < C::NP; q++) {
-        const f2 vv = vrow[st % (LA + 1)][q];
-        const int ch = (a * C::NP + q) & 1;
-        s_x[ch] = fma2(mk2(vv.x, vv.x), wab[a][2 * q], s_x[ch]);
-        s_y[ch] = fma2(mk2(vv.y, vv.y), wab[a][2 * q + 1], s_y[ch]);
-        s_p[ch] = fma2(vv, wc[a][q], s_p[ch]);
-        GA_SCHED_FENCE();
-        if (a == R && 2 * q <= R && R <= 2 * q + 1) {
-          const float c0 = (R & 1) ? vv.y : vv.x;
-          xc = par ? xc : c0;
-        }
-        if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
-          const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
-          xc = par ? c1 : xc;
-        }
-      }
-      if (a == C::WS - 1) {
-        const int d = v_lo + k;
-        GA_KEEP_F2(s_x[0]); GA_KEEP_F2(s_x[1]); GA_KEEP_F2(s_y[0]); GA_KEEP_F2(s_y[1]); GA_KEEP_F2(s_p[0]); GA_KEEP_F2(s_p[1]);
-        const f2 t_x = add2(s_x[0], s_x[1]), t_y = add2(s_y[0], s_y[1]), t_p = add2(s_p[0], s_p[1]);
-        const float zm = t_x.x + t_y.x;                       // depth slab -1 -> y[d+1]
-        const float z0 = t_x.y + t_y.y;                       // depth slab  0 -> y[d]
-        const float zp = t_p.x + t_p.y;                       // depth slab +1 -> y[d-1]
-        const bool live = d <= v_hi;                          // uniform
-        if (live && d - 1 >= d_lo) {
-          const int dy = d - 1;
-          float cc = cmid;
-          if (dy == 0) cc += sin_m;
-          const float r = fmaf(xc_prev, cc, acc_a + zp);
-#if LGA_ABLATE & 2
-          if (inb && r == 123.456f) *yp = r;
-#else
-          if (inb) *yp = r;
-#endif
-          GA_DMA_MASKED(1);                                   // (emulator: the y store is one more operation the relaxed wait counts)
-          yp += geo.HW;
-        }
-        acc_a = live ? acc_b + z0 : acc_a;
-        acc_b = live ? zm : acc_b;
-        xc_prev = live ? xc : xc_prev;
-        slot_c = slot_n;
-      }
-    }
-  }
-  if (d_hi == geo.D) {
-    const int dy = geo.D - 1;
-    float cc = cmid + sin_p;
-    if (dy == 0) cc += sin_m;
-    const float r = fmaf(xc_prev, cc, acc_a);
-    if (inb) *yp = r;
-  }
-  GA_VMCNT(0);      // no DMA may still be in flight when the wave's LDS is handed to the next workgroup
-}
 
 
 // ---- wave-autonomous forward / data-backward, PLANE-PAIR packing ----------------------------------------
@@ -1186,229 +734,6 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
 #undef GA_FG_GYP
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
-
-// one 4-byte global -> LDS copy per lane: lane l's dword lands at slot + 4 * l
-GA_DEV void lga_dma4(const float *gsrc, float *slot, int lane)
-{
-#if defined(GA_HIPSIM)
-  hipsim::dma_issue(slot + lane, gsrc, 1);
-#else
-  (void)lane;
-  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
-}
-
-// ---- filter backward, wave-autonomous with LDS-DMA staging -----------------------------------
-// Same decomposition as lga_apply_dma (one wave = one 32 x 2 pixel tile, private plane ring, no
-// barrier, no staging registers), no depth segments (the 3K sums of a pixel run over all of D).  The
-// halo'd x plane arrives by one global_load_lds_dwordx4, the lane's own gy value by one
-// global_load_lds_dword into a second ring that runs one plane ahead (plane k pairs with gy[k-1],
-// gy[k], gy[k+1]).  Every vector-memory operation of the march is one of those two, issued in the
-// fixed order gy(k+1), x(k), so the in-order counter tells exactly what has landed: once x(j) is in,
-// so are gy(0..j+1), and after x(j) come two operations for each later plane.
-// The 256-thread tile kernel below spends its barriers and staging VALU on the same copies
-// (37 % of its wave time parked, profiles/r1m_pmc_summary.txt).
-#ifndef LGAF_NR
-#define LGAF_NR 8                // x-plane ring slots per wave (960 B each at R = 2; + 9 gy slots of 256 B: ~10 KB per wave)
-#endif
-template <int R>
-__global__ void __launch_bounds__(64, (R <= 2 ? LGA_WAVES_PER_SIMD : 1))
-lga_filter_grad_dma(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gf,
-                    LgaGeom geo, LgaSeg sg, int accumulate)
-{
-  typedef LgaCfg<R> C;
-  typedef LgaDCfg<R> DC;
-  static_assert(DC::OK, "one DMA instruction must cover a plane");
-  constexpr int NR = LGAF_NR, P = NR - 1, NG_ = NR + 1;
-  __shared__ __attribute__((aligned(16))) float ring[NR * DC::PLANE];
-  __shared__ __attribute__((aligned(16))) float gring[NG_ * 64];
-  const int lane = threadIdx.x;                       // blockDim.x == 64
-  const int tx = lane % LGA_TW, ty = lane / LGA_TW;
-  int item = xcd_remap(blockIdx.x, gridDim.x);        // tiles along a row first; each XCD a contiguous band
-  const int bx = item % sg.tiles_x; item /= sg.tiles_x;
-  const int by = item % sg.tiles_y;
-  const int b = item / sg.tiles_y;
-  const int tx0 = bx * LGA_TW, ty0 = by * LGAW_TH;
-  const int i = ty0 + ty, j = tx0 + tx;
-  const bool inb = i < geo.H && j < geo.W;
-  const int ic = i < geo.H ? i : geo.H - 1, jc = j < geo.W ? j : geo.W - 1;
-  const float *xb = x + (i64)b * geo.D * geo.HW;
-  const float *gyb = gy + (i64)b * geo.D * geo.HW;
-  float *gfb = gf + (i64)b * 3 * C::K * geo.HW;
-  const i64 pix = (i64)ic * geo.W + jc;
-  const int wcol = tx + DC::HALO - R;
-  const int par = wcol & 1;
-  const int rcol = wcol - par;
-  const int D = geo.D;
-
-  // clear the x ring (cells of out-of-image groups are never written again), then fill the pipeline
-#pragma unroll
-  for (int k = 0; k < (NR * DC::PLANE / 4 + 63) / 64; k++) {
-    const int e = k * 64 + lane;
-    if (e < NR * DC::PLANE / 4) *reinterpret_cast<f4 *>(ring + 4 * e) = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  GA_LGKMCNT0();
-  GA_WAVE_SYNC();
-  bool dma_on = false;
-  const float *gsrc = xb;
-  if (lane < DC::NG) {
-    const int r = lane / DC::G, c4 = lane - r * DC::G;
-    const int i2 = ty0 + r - R, j2 = tx0 - DC::HALO + 4 * c4;      // W % 4 == 0: a group is in or out as a whole
-    if (i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W) {
-      dma_on = true;
-      gsrc = xb + (i64)i2 * geo.W + j2;
-    }
-  }
-  const float *gysrc = gyb + pix;
-  int dma_slot = 0, g_slot = 0;
-  // x plane k (repeats the last plane past the end so that the operation count per step stays fixed)
-  auto dma_x = [&](int k) {
-    if (dma_on) lga_dma16(gsrc, ring + dma_slot * DC::PLANE, lane);
-    else GA_DMA_MASKED(1);
-    gsrc += k + 1 < D ? geo.HW : 0;
-    dma_slot = dma_slot + 1 == NR ? 0 : dma_slot + 1;
-  };
-  auto dma_g = [&](int k) {                            // gy plane k (clamped; its value is masked where k >= D)
-    lga_dma4(gysrc, gring + g_slot * 64, lane);
-    gysrc += k + 1 < D ? geo.HW : 0;
-    g_slot = g_slot + 1 == NG_ ? 0 : g_slot + 1;
-  };
-  dma_g(0);
-  for (int k = 0; k < P; k++) { dma_g(k + 1); dma_x(k); }
-
-  // partial sums per window slot: sab[a][k] = (slab -1, slab 0), sc[a][q] = slab +1 of (2q, 2q+1)
-  f2 sab[C::WS][C::NK], sc[C::WS][C::NP];
-#pragma unroll
-  for (int a = 0; a < C::WS; a++) {
-#pragma unroll
-    for (int k = 0; k < C::NK; k++) sab[a][k] = mk2(0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < C::NP; q++) sc[a][q] = mk2(0.f, 0.f);
-  }
-  float gc = 0.f;                 // sum_d gy[d] * x[d][centre]
-  float e_lo = 0.f, e_hi = 0.f;   // gy[0]*x[0][c], gy[D-1]*x[D-1][c]
-
-  constexpr int LA = LGAW_LA, U = LA + 1, NSTEP = U * C::WS;
-  static_assert(C::WS > LA, "look-ahead must stay within the next plane");
-  const lds_cptr lbase = GA_LDS_CPTR(&ring[0]) + ty * DC::TW2 + rcol;
-  const lds_cptr gbase = GA_LDS_CPTR(&gring[0]) + lane;
-  f2 vrow[LA + 1][C::NP];
-  GA_VMCNT(2 * P - 2);                                     // x(0), gy(0), gy(1) have landed
-  GA_WAVE_SYNC();
-#pragma unroll
-  for (int s0 = 0; s0 < LA; s0++) {
-#pragma unroll
-    for (int q = 0; q < C::NP; q++) vrow[s0][q] = lds_read_b64(lbase + s0 * DC::TW2 + 2 * q);
-  }
-  float g_m = 0.f, g_0 = gbase[0];
-  int slot_c = 0;                                // ring slot of the x plane being visited
-  int gs_n = 1;                                  // gy ring slot of plane k + 1
-  for (int k0 = 0; k0 < D; k0 += U) {
-    float xc = 0.f, g_p = 0.f;
-    f2 g01 = mk2(0.f, 0.f), gmm = mk2(0.f, 0.f);
-#pragma unroll
-    for (int st = 0; st < NSTEP; st++) {
-      const int u = st / C::WS, a = st % C::WS;
-      const int k = k0 + u;
-      const bool live = k < D;                               // uniform
-      if (a == 0) {
-        // the slots these overwrite held x(k-1) and gy(k-2), both consumed
-        dma_g(k + P + 1);
-        dma_x(k + P);
-        const float gv = gbase[gs_n * 64];                   // gy[k+1]: issued before x(k), which has landed (see below)
-        g_p = k + 1 < D ? gv : 0.f;
-        g01 = mk2(g_p, g_0);                                 // plane k pairs with gy[k+1] (slab -1), gy[k] (slab 0)
-        gmm = mk2(g_m, g_m);                                 // ... and gy[k-1] (slab +1)
-      }
-      const int slot_n = slot_c + 1 == NR ? 0 : slot_c + 1;
-      const lds_cptr cur = lbase + slot_c * DC::PLANE, nxt = lbase + slot_n * DC::PLANE;
-      if (a == C::WS - LA) {
-        // x(k+1) -- and with it gy(k+2), issued just before it -- must have landed: after x(k+1) came
-        // two operations for each of the planes k+2 .. k+P
-        GA_VMCNT(2 * P - 2);
-        GA_WAVE_SYNC();
-      }
-      {
-        const int t = a + LA;
-        const lds_cptr src = t < C::WS ? cur + t * DC::TW2 : nxt + (t - C::WS) * DC::TW2;
-#pragma unroll
-        for (int q = 0; q < C::NP; q++) vrow[(st + LA) % (LA + 1)][q] = lds_read_b64(src + 2 * q);
-      }
-      GA_SCHED_FENCE();
-      if (live) {
-#pragma unroll
-        for (int q = 0; q < C::NP; q++) {
-          const f2 vv = vrow[st % (LA + 1)][q];
-          sab[a][2 * q] = fma2(mk2(vv.x, vv.x), g01, sab[a][2 * q]);
-          sab[a][2 * q + 1] = fma2(mk2(vv.y, vv.y), g01, sab[a][2 * q + 1]);
-          sc[a][q] = fma2(vv, gmm, sc[a][q]);
-          if (a == R && 2 * q <= R && R <= 2 * q + 1) {
-            const float c0 = (R & 1) ? vv.y : vv.x;
-            xc = par ? xc : c0;
-          }
-          if (a == R && 2 * q <= R + 1 && R + 1 <= 2 * q + 1) {
-            const float c1 = ((R + 1) & 1) ? vv.y : vv.x;
-            xc = par ? c1 : xc;
-          }
-        }
-      }
-      if (a == C::WS - 1) {
-        if (live) {
-          const float e = g_0 * xc;
-          gc += e;
-          if (k == 0) e_lo = e;
-          if (k == D - 1) e_hi = e;
-          g_m = g_0;
-          g_0 = g_p;
-        }
-        slot_c = slot_n;
-        gs_n = gs_n + 1 == NG_ ? 0 : gs_n + 1;
-      }
-    }
-  }
-  GA_VMCNT(0);      // no DMA may still be in flight when the wave's LDS is handed to the next workgroup
-
-  if (inb) {
-#pragma unroll
-    for (int dd = 0; dd < 3; dd++) {
-      // accumulate mode: the K old values of this depth slab are loaded together, then added and stored
-      // (written as `*dst = accumulate ? *dst + r : r` every tap is load -> s_waitcnt vmcnt(0) -> store:
-      // 75 serial round trips per lane, +30 us on the second pass of an LGA2 backward)
-      float old[C::K];
-#pragma unroll
-      for (int k = 0; k < C::K; k++) old[k] = 0.f;
-      if (accumulate) {
-#pragma unroll
-        for (int k = 0; k < C::K; k++) old[k] = gfb[(i64)(dd * C::K + k) * geo.HW + pix];
-      }
-#pragma unroll
-      for (int a = -R; a <= R; a++) {
-#pragma unroll
-        for (int bb = -R; bb <= R; bb++) {
-          const int t = dd * C::K + (a + R) * C::WS + (bb + R);
-          const int i2 = i + a, j2 = j + bb;
-          const bool ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
-          const int ke = bb + R, ko = bb + R + 1, ra = a + R;
-          float re, ro;
-          if (dd == 0) { re = sab[ra][ke].x; ro = sab[ra][ko].x; }
-          else if (dd == 1) { re = sab[ra][ke].y; ro = sab[ra][ko].y; }
-          else {
-            re = (ke & 1) ? sc[ra][ke >> 1].y : sc[ra][ke >> 1].x;
-            ro = (ko & 1) ? sc[ra][ko >> 1].y : sc[ra][ko >> 1].x;
-          }
-          float r = par ? ro : re;
-          if (dd == 0) r += e_lo;
-          if (dd == 2) r += e_hi;
-          if (!ok) r = gc;
-          gfb[(i64)t * geo.HW + pix] = old[(a + R) * C::WS + (bb + R)] + r;
-        }
-      }
-    }
-  }
-}
 
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)

@@ -107,6 +107,48 @@ def all_reduce_mean_(tensors, ctx, bucket_bytes=64 << 20):
     flush()
 
 
+GRAD_ELEMS_GANET_DEEP = 6580112      # fp32 parameters of GANet-deep = its gradient all-reduce (26.3 MB)
+
+
+def allreduce_probe(ctx, backend, device, nelem=GRAD_ELEMS_GANET_DEEP, iters=10, bucket_bytes=64 << 20):
+    """The one collective a data-parallel caller of this path runs per step -- the parameter-gradient mean (the reference:
+    nn.DataParallel's reduce, train.py:73) -- measured on its own: `nelem` fp32 values through all_reduce_mean_ on a process
+    group of `backend` ("nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests).  Every rank calls it.  Returns
+    {backend, ranks, bytes, allreduce_ms, algbw_GBs, busbw_GBs} (busbw = 2 (N-1)/N x bytes / time: per-link traffic of a
+    ring), max over ranks, or {"error": ...} when the group cannot be made (the benchmark's own number never depends on it)."""
+    if ctx.world_size == 1:
+        return None
+    try:
+        group = dist.new_group(backend=backend) if dist.get_backend() != backend else None
+        g = torch.ones(nelem, dtype=torch.float32, device=device) * (ctx.rank + 1)
+
+        def once():
+            if group is None:
+                all_reduce_mean_([g], ctx, bucket_bytes)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+                g.div_(ctx.world_size)
+        sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+        once()                                           # connection set-up is not part of the rate
+        sync()
+        want = (ctx.world_size + 1) / 2.0                # mean of rank + 1
+        ok = bool(torch.allclose(g[:16].float().cpu(), torch.full((16,), want)))
+        g.fill_(1.0)
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            once()
+        sync()
+        dt = max_over_ranks(ctx, (time.perf_counter() - t0) / iters, device=torch.device("cpu") if dist.get_backend() == "gloo" else None)
+        nbytes = nelem * 4
+        return {"backend": "rccl (nccl)" if backend == "nccl" else backend, "ranks": ctx.world_size, "bytes": nbytes,
+                "allreduce_ms": round(1e3 * dt, 4), "algbw_GBs": round(nbytes / dt / 1e9, 2),
+                "busbw_GBs": round(2.0 * (ctx.world_size - 1) / ctx.world_size * nbytes / dt / 1e9, 2), "result_ok": ok}
+    except Exception as e:                               # noqa: BLE001  (reported, never fatal for the op benchmark)
+        return {"backend": backend, "ranks": ctx.world_size, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def finish(ctx):
     if ctx.initialized_here and dist.is_initialized():
         dist.destroy_process_group()

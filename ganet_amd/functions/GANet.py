@@ -50,6 +50,27 @@ def _p(t):
     return t.data_ptr()
 
 
+def _sga_infer(input, g0, g1, g2, g3, output, bn_scale=None, bn_shift=None):
+    """ganet_sga_forward_infer with the scratch its dispatch asks for.  The size query and the call read the library's
+    options separately (ganet_set_option from another thread may fall between them: ADVICE r2), so a call that finds its
+    scratch missing is repeated once with the full four-volume scratch instead of failing."""
+    N, C, D, H, W = input.shape
+    lib = _lib()
+    nws = lib.query("ganet_sga_forward_infer_scratch", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(output), N, C, D, H, W)
+    for attempt in (0, 1):
+        A = torch.empty((nws,) + tuple(input.shape), dtype=input.dtype, device=input.device) if nws else None
+        try:
+            lib.call("ganet_sga_forward_infer", _p(input), _p(g0), _p(g1), _p(g2), _p(g3), _p(A) if nws else None, _p(output),
+                     _p(bn_scale) if bn_scale is not None else None, _p(bn_shift) if bn_shift is not None else None,
+                     N, C, D, H, W, _stream())
+            return output
+        except _native.GanetError as e:
+            if attempt or nws or e.code != _native.E_INVALID or "scratch" not in str(e):
+                raise
+            nws = 4
+    return output
+
+
 class SgaFunction(Function):
     """SgaFunction.apply(input, g0, g1, g2, g3) -> output   (functions/GANet.py:8-48).
 
@@ -71,12 +92,7 @@ class SgaFunction(Function):
             if not any(ctx.needs_input_grad):
                 # nothing to differentiate (torch.no_grad() as in predict.py:113, or no input requires grad): the scans keep
                 # a running direction maximum -- four launches, no directional volumes, no mask / arg-max kept
-                nws = _lib().query("ganet_sga_forward_infer_scratch", _p(input), _p(g0), _p(g1), _p(g2), _p(g3),
-                                   _p(output), N, C, D, H, W)
-                A = torch.empty((nws,) + tuple(input.shape), dtype=input.dtype, device=input.device) if nws else None
-                _lib().call("ganet_sga_forward_infer", _p(input), _p(g0), _p(g1), _p(g2), _p(g3),
-                            _p(A) if nws else 0, _p(output), 0, 0, N, C, D, H, W, _stream())
-                return output
+                return _sga_infer(input, g0, g1, g2, g3, output)
             if ctx.recompute:
                 temp_out = torch.empty_like(input)
                 mask = torch.empty_like(input)
@@ -133,10 +149,11 @@ def _lga_dims(input, filters, radius):
 
 
 def _paired_intermediate(passes, radius, W):
-    """GANET_LGA_PAIRED=1 (default off: built and checked on the kernel emulator, not yet measured on a GPU): a two-pass
-    chain keeps its private intermediate volume pair-interleaved (include/ganet_hip.h, ganet_lga_apply_paired), which the second
-    pass and the filter gradient stage with two 16-byte copies per plane pair instead of seven 4-byte ones."""
-    return passes == 2 and radius == 2 and W % 2 == 0 and os.environ.get("GANET_LGA_PAIRED", "0") == "1"
+    """A two-pass chain keeps its private intermediate volume (and that volume's gradient) pair-interleaved
+    (include/ganet_hip.h, ganet_lga_apply_paired): the second pass and the filter gradient stage a plane pair with two 16-byte
+    copies instead of seven 4-byte ones.  Measured (profiles/r3a_check_lga_paired.txt): Lga2Function fwd+bwd 0.684 -> 0.637 ms at
+    [1,193,240,624], 4.24 -> 3.97 ms at [2,193,528,960], results identical.  GANET_LGA_PAIRED=0 switches it off (tests)."""
+    return passes == 2 and radius == 2 and W % 2 == 0 and os.environ.get("GANET_LGA_PAIRED", "1") != "0"
 
 
 class _LgaChain(Function):

@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _native
-from .GANet import _check, _p, _stream
+from .GANet import _check, _p, _sga_infer, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
            "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction", "LgaRegressFunction"]
@@ -115,12 +115,7 @@ def sga_forward_infer(x, g0, g1, g2, g3, bn_scale=None, bn_shift=None):
     if bn_scale is not None and (bn_scale.numel() != C or bn_shift.numel() != C):
         raise ValueError("bn_scale / bn_shift must have one entry per channel")
     with torch.cuda.device_of(x):
-        out = torch.empty_like(x)
-        nws = _lib().query("ganet_sga_forward_infer_scratch", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(out), N, C, D, H, W)
-        A = torch.empty((nws,) + tuple(x.shape), dtype=x.dtype, device=x.device) if nws else None
-        _lib().call("ganet_sga_forward_infer", _p(x), _p(g0), _p(g1), _p(g2), _p(g3), _p(A) if nws else None, _p(out),
-                    _p(bn_scale) if bn_scale is not None else None, _p(bn_shift) if bn_shift is not None else None,
-                    N, C, D, H, W, _stream())
+        out = _sga_infer(x, g0, g1, g2, g3, torch.empty_like(x), bn_scale, bn_shift)
     return out
 
 

@@ -61,14 +61,25 @@ def train_step(model, optimizer, name, left, right, target, max_disp, crit):
     """One optimisation step (train.py:85-120).  Returns (loss, mean abs error of the last disparity)."""
     model.train()
     mask = (target < max_disp).detach()
-    if int(mask.sum()) == 0:
+    # train.py:97-99 skips a batch without valid pixels.  With one process per GPU the skip has to be COLLECTIVE: a rank that
+    # returned early would leave the others waiting in the gradient all-reduce (ADVICE r2).  The step is skipped only if no
+    # rank has a valid pixel; a rank whose own shard is empty runs forward + backward with a zero-weighted loss.
+    nvalid = mask.sum()
+    total = nvalid.clone()
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        torch.distributed.all_reduce(total)
+    if int(total) == 0:
         return None, None
     optimizer.zero_grad()
     outputs = model(left, right)
-    loss = loss_mix(name, outputs, target, mask, crit)
+    if int(nvalid) == 0:
+        loss = sum(o.sum() for o in outputs) * 0.0
+        err = loss.detach()
+    else:
+        loss = loss_mix(name, outputs, target, mask, crit)
+        err = torch.mean(torch.abs(outputs[-1][mask] - target[mask])).detach()
     loss.backward()
     optimizer.step()
-    err = torch.mean(torch.abs(outputs[-1][mask] - target[mask])).detach()
     return loss.detach(), err
 
 

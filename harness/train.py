@@ -85,7 +85,8 @@ def run(args, hook=None):
     def timed():
         for _ in range(args.steps):
             loss, err = steps.train_step(model, opt, args.model, left, right, target, args.max_disp, crit)
-            losses.append(float(loss))
+            if loss is not None:      # (a step every rank skipped: no valid pixel anywhere)
+                losses.append(float(loss))
 
     elapsed = gdist.timed_region(ctx, timed, sync=sync)
     share = None

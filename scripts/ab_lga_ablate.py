@@ -1,4 +1,4 @@
-"""Forward-pass time of lga_apply_pp (GANET_LGA_WAVE=3, one depth segment) for several builds of the library
+"""Forward-pass time of lga_apply_pp (whole tiles, one depth segment) for several builds of the library
 (scripts/build_variants.py tags with -DLGAP_ABLATE=<bits>): python scripts/ab_lga_ablate.py lib1.so lib2.so ..."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ for rep in range(2):
     for name in sys.argv[1:]:
         lib = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
         for segs in (1, 0):
-            lib.set_option("GANET_LGA_WAVE", 3); lib.set_option("GANET_LGA_SEGS", segs)
+            lib.set_option("GANET_LGA_MIX", 0); lib.set_option("GANET_LGA_SEGS", segs)
             fn = lambda: lib.call("ganet_lga_forward", x.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, st)
             fn(); fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

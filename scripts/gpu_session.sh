@@ -1,6 +1,6 @@
 #!/bin/bash
-# One GPU session of round 2.  gpurun --timeout N -- 'bash scripts/gpu_round2.sh <tag> [parts]'
-#   parts: any of  ubench tests smoke bench prof model modelprof  (default: all but ubench/modelprof)
+# One GPU session.  gpurun --timeout N -- 'bash scripts/gpu_session.sh <tag> [parts]'
+#   parts: any of  ubench tests smoke bench prof pmc modeltests model nofind  (default: tests smoke bench prof model)
 # Everything worth keeping goes to gpurun_out/<tag>/ (merged back into the dev container).
 TAG=${1:-r2}
 PARTS=${2:-"tests smoke bench prof model"}
@@ -54,14 +54,6 @@ if has pmc; then
   python scripts/pmc_summary.py $OUT/pmc > $OUT/pmc/summary.txt 2>&1
   python scripts/pmc_traffic.py $OUT/pmc/summary.txt $OUT/traffic_pmc.json > /dev/null 2>&1; echo "traffic rc=$?"
   find $OUT/pmc -name '*.csv' -size +2M -delete 2>/dev/null
-fi
-if has ablga; then
-  echo "== LGA kernel families A/B"
-  timeout 400 python scripts/ab_lga.py > $OUT/ab_lga.txt 2>&1; echo "ab_lga rc=$?"; grep -v amdgpu.ids $OUT/ab_lga.txt
-  for v in ganet_amd/libganet_hip_*.so; do
-    [ -f $v ] || continue
-    n=$(basename $v); timeout 300 python scripts/ab_lga.py --lib=$n > $OUT/ab_lga_$n.txt 2>&1; echo "ab_lga $n rc=$?"; grep -v amdgpu.ids $OUT/ab_lga_$n.txt
-  done
 fi
 if has modeltests; then
   echo "== model tests (reference models on the drop-in, GPU vs CPU-oracle twin)"

@@ -200,6 +200,29 @@ def check_lga_chain(api, dev, x, f, gy, r, passes, want):
     return err
 
 
+def check_lga2_paired(api, dev, x, f, gy, r, passes, want):
+    """The call sequence of Lga2Function with its private intermediate (and the intermediate's gradient) pair-interleaved
+    (ganet_amd/functions/GANet.py: _LgaChain): x -> t1 (interleaved) -> y;  gf = gF(t1, gy);  g_t1 (interleaved) = gX(gy);
+    gf += gF(x, g_t1);  gx = gX(g_t1).  Radius 2, two passes, even W."""
+    assert r == 2 and passes == 2
+    B, D, H, W = lga_dims(x)
+    dx, df, dgy = dev.to(x), dev.to(f), dev.to(gy)
+    pshape = (B, (D + 1) // 2, H, W, 2)
+    t1p, y = dev.empty(pshape), dev.empty(x.shape)
+    api.call("ganet_lga_apply_paired", dev.ptr(dx), dev.ptr(df), dev.ptr(t1p), B, D, H, W, 2, 0, 0, 1, dev.stream)
+    api.call("ganet_lga_apply_paired", dev.ptr(t1p), dev.ptr(df), dev.ptr(y), B, D, H, W, 2, 0, 1, 0, dev.stream)
+    gf, gt1p, gx = dev.empty(f.shape), dev.empty(pshape), dev.empty(x.shape)
+    api.call("ganet_lga_filter_grad_paired", dev.ptr(t1p), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, 1, 0, dev.stream)
+    api.call("ganet_lga_apply_paired", dev.ptr(dgy), dev.ptr(df), dev.ptr(gt1p), B, D, H, W, 2, 1, 0, 1, dev.stream)
+    api.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(gt1p), dev.ptr(gf), B, D, H, W, 2, 1, 0, 1, dev.stream)
+    api.call("ganet_lga_apply_paired", dev.ptr(gt1p), dev.ptr(df), dev.ptr(gx), B, D, H, W, 2, 1, 1, 0, dev.stream)
+    dev.sync()
+    err = {"y": float(np.abs(dev.host(y) - want["y"]).max()), "gx": float(np.abs(dev.host(gx) - want["gx"]).max()),
+           "gf": float(np.abs(dev.host(gf) - want["gf"]).max())}
+    assert max(err.values()) <= TOL, err
+    return err
+
+
 def to_paired(v):
     """[B, D, H, W] -> the pair-interleaved layout [B, ceil(D/2), H, W, 2] of ganet_lga_apply_paired (odd D: zero odd half)."""
     B, D, H, W = v.shape

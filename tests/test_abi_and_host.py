@@ -54,7 +54,8 @@ def test_library_contains_gfx950_code_object(built_lib):
 def test_reference_names_are_mirrored():
     import ganet_amd.functions.GANet as Fn
     import ganet_amd.modules.GANet as M
-    from ganet_amd import ext
+    import torch  # noqa: F401  (libtorch must be mapped before the pybind module)
+    from libs.GANet.build.lib import GANet as ext      # the reference's native surface: pybind module on the C ABI
     for n in ["SgaFunction", "LgaFunction", "Lga2Function", "Lga3Function", "Lga3dFunction", "Lga3d2Function",
               "Lga3d3Function", "MyLossFunction", "MyLoss2Function"]:
         assert hasattr(Fn, n)

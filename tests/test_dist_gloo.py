@@ -30,6 +30,10 @@ def _worker(rank, world, port, q):
     lo, hi = gdist.shard_range(7, ctx)
     grads = [torch.full((5,), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))]
     gdist.all_reduce_mean_(grads, ctx, bucket_bytes=16)
+    probe = gdist.allreduce_probe(ctx, "gloo", torch.device("cpu"), nelem=1000, iters=2)
+    assert probe["ranks"] == world and probe["result_ok"] and probe["bytes"] == 4000, probe
+    bad = gdist.allreduce_probe(ctx, "no-such-backend", torch.device("cpu"), nelem=10, iters=1)
+    assert "error" in bad, bad                      # reported, never fatal
     q.put((rank, t, (lo, hi), [g.tolist() for g in grads]))      # plain lists: a tensor in the queue is handed over
     # through the sender's resource-sharer socket, which is gone if this process exits before the parent reads it
     gdist.finish(ctx)
@@ -86,3 +90,60 @@ def test_bench_gpus2_plumbing_with_stub_step(launcher):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]
+    # the gradient all-reduce probe bench.py runs after the timed region (RCCL on GPUs; here its code path over gloo)
+    probe = line["rccl"]
+    assert "error" not in probe, probe
+    assert probe["ranks"] == 2 and probe["result_ok"] and probe["allreduce_ms"] > 0
+    assert abs(probe["busbw_GBs"] - probe["algbw_GBs"]) <= 0.02 * probe["algbw_GBs"] + 0.01      # 2 (N-1)/N = 1 at N = 2
+
+
+def _skip_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from harness import steps
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Toy(torch.nn.Module):                      # two disparity maps, like GANet11
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(6, 2, 3, padding=1)
+
+        def forward(self, left, right):
+            o = self.c(torch.cat([left, right], 1))
+            return o[:, 0], o[:, 1]
+    torch.manual_seed(0)
+    model = DDP(Toy())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    max_disp = 24
+    left, right, target = steps.synthetic_batch(1, 8, 12, max_disp, "cpu", seed=rank)
+    crit = lambda a, b: torch.nn.functional.smooth_l1_loss(a, b)      # noqa: E731
+    out = []
+    # step 1: rank 1 has no valid pixel (its shard alone would be skipped), rank 0 has: both must run the step
+    t1 = torch.full_like(target, float(max_disp)) if rank == 1 else target
+    out.append(steps.train_step(model, opt, "GANet11", left, right, t1, max_disp, crit)[0] is not None)
+    # step 2: no rank has a valid pixel: both skip
+    out.append(steps.train_step(model, opt, "GANet11", left, right, torch.full_like(target, float(max_disp)), max_disp, crit)[0] is None)
+    digest = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    q.put((rank, out, digest))
+    dist.destroy_process_group()
+
+
+def test_batch_without_valid_pixels_is_skipped_collectively():
+    """harness.steps.train_step under DDP: a rank whose shard has no valid pixel must not leave the others
+    waiting in the gradient all-reduce; the step is skipped only when every rank is empty."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_skip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [True, True] and res[1][1] == [True, True]
+    assert res[0][2] == res[1][2], "identical parameters after the shared step"

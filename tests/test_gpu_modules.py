@@ -1,4 +1,4 @@
-"""GPU tests of the drop-in operator API (ganet_amd.functions / ganet_amd.modules / ganet_amd.ext,
+"""GPU tests of the drop-in operator API (ganet_amd.functions / ganet_amd.modules / the pybind module GANet,
 mirroring libs/GANet/{functions,modules}/GANet.py and the pybind module of GANet_cuda.cpp)."""
 import numpy as np
 import pytest
@@ -106,7 +106,7 @@ def test_ext_module_reference_buffer_contract(torch_mod, port_oracle):
     functions/GANet.py calls them (zero-filled caller buffers, aliasing in the LGA2 backward)."""
     torch = torch_mod
     import torch.nn.functional as F
-    from ganet_amd import ext as GANet
+    from libs.GANet.build.lib import GANet          # the pybind module (ganet_amd/csrc/ganet_torch_ext.cpp), where the reference imports it from
     torch.manual_seed(3)
     x = torch.randn(1, 2, 17, 6, 12, device="cuda")
     gs = [F.normalize(torch.randn(1, 2, 5, 6, 12, device="cuda"), p=1, dim=2) for _ in range(4)]

@@ -42,17 +42,15 @@ def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
     assert max(err.values()) < 2e-5, err
 
 
-@pytest.mark.parametrize("wave,segs", [(0, 0), (1, 1), (1, 2), (1, 3), (1, 5), (1, 64), (2, 1), (2, 2), (2, 3), (2, 64),
-                                       (3, 1), (3, 2), (3, 3), (3, 5), (3, 64)])
+@pytest.mark.parametrize("wave,segs", [(0, 0), (1, 1), (1, 2), (1, 3), (1, 5), (1, 64)])
 @pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 5, 2, 36), 3),
                                      ((1, 1, 3, 32), 2), ((1, 9, 1, 2), 2), ((1, 31, 3, 8), 2), ((1, 14, 2, 4), 1),
                                      ((1, 12, 3, 33), 2), ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2)])
 def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave, segs):
-    """256-thread tile kernels (0) vs the wave-autonomous kernels with register staging (1), with the
-    LDS-DMA plane ring (2; widths that are not a multiple of 4 fall back to 1) and with plane-pair packing (3: forward and
-    data-backward; any width; segments start on even planes), the latter three with the
-    disparity range cut into 1..D segments (every seam, single-plane segments, more segments than
-    planes) and more planes than ring slots."""
+    """256-thread tile kernels (GANET_LGA_WAVE=0, the fallback) vs the wave-autonomous plane-pair kernels (1, the default:
+    forward and data-backward; any width; segments start on even planes; radius 3 falls back to the tile kernels), the latter
+    with the disparity range cut into 1..D segments (every seam, single-pair segments, more segments than planes) and more
+    planes than ring slots."""
     rng = np.random.default_rng(sum(shape) + r)
     fs = list(shape)
     fs[1] = 3 * (2 * r + 1) ** 2
@@ -67,7 +65,7 @@ def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave
         err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 3)
+        sim.set_option("GANET_LGA_WAVE", 1)
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
@@ -108,35 +106,12 @@ def test_lga_unsupported_radius(sim):
         sim.call("ganet_lga_forward", x.ctypes.data, x.ctypes.data, x.ctypes.data + 4, 1, 2, 2, 2, 4, None)
 
 
-@pytest.mark.parametrize("wave", [2, 3])
-@pytest.mark.parametrize("split", [1, 4, 8])
-def test_unequal_depth_split_of_the_wave_kernels(sim, port_oracle, split, wave):
-    """Two unequal depth segments per tile ([0, split) and [split, D), all first segments dispatched first): the
-    forward and the data-backward must not depend on where the volume is cut."""
-    import parity_cases as pc
-    rng = np.random.default_rng(split)
-    shape = (2, 9, 6, 40)
-    x = rng.standard_normal(shape).astype(np.float32)
-    f = pc.l1norm(rng.standard_normal((2, 75, 6, 40)), 1)
-    gy = rng.standard_normal(shape).astype(np.float32)
-    y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
-    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
-    sim.set_option("GANET_LGA_SPLIT", split)
-    sim.set_option("GANET_LGA_WAVE", wave)
-    try:
-        pc.check_lga_chain(sim, pc.NumpyDev(), x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
-    finally:
-        sim.set_option("GANET_LGA_SPLIT", 1)
-        sim.set_option("GANET_LGA_WAVE", 3)
-
-
-@pytest.mark.parametrize("wps", [2, 3])
 @pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 1, 3, 32), 2),
                                      ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2)])
-def test_plane_pair_filter_gradient_variants(sim, port_oracle, shape, r, wps):
-    """lga_filter_grad_pp in both register budgets (3 waves per SIMD without LDS look-ahead, 2 with two rows): odd and even
-    D (a last pair with one real plane), more pairs than ring slots, accumulate mode through a two-pass chain."""
-    rng = np.random.default_rng(sum(shape) + r + wps)
+def test_plane_pair_filter_gradient(sim, port_oracle, shape, r):
+    """lga_filter_grad_pp: odd and even D (a last pair with one real plane), more pairs than ring slots, accumulate mode
+    through a two-pass chain."""
+    rng = np.random.default_rng(sum(shape) + r)
     fs = list(shape)
     fs[1] = 3 * (2 * r + 1) ** 2
     x = rng.standard_normal(shape).astype(np.float32)
@@ -144,46 +119,39 @@ def test_plane_pair_filter_gradient_variants(sim, port_oracle, shape, r, wps):
     gy = rng.standard_normal(shape).astype(np.float32)
     y, ins = port_oracle.lga_chain_forward(x, f, r, 2)
     gx, gf = port_oracle.lga_chain_backward(ins, f, gy, r)
-    sim.set_option("GANET_LGA_WAVE", 3)
-    sim.set_option("GANET_LGA_FG_WPS", wps)
-    try:
-        err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 2, {"y": y, "gx": gx, "gf": gf})
-        assert max(err.values()) < 2e-5, err
-    finally:
-        sim.set_option("GANET_LGA_WAVE", 3)
-        sim.set_option("GANET_LGA_FG_WPS", 3)
+    err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 2, {"y": y, "gx": gx, "gf": gf})
+    assert max(err.values()) < 2e-5, err
 
 
-@pytest.mark.parametrize("segs,split", [(1, 1), (2, 1), (0, 24), (0, 40)])
+@pytest.mark.parametrize("segs", [1, 2, 3])
 @pytest.mark.parametrize("shape", [(1, 65, 3, 34), (1, 64, 2, 36), (2, 47, 2, 40)])
-def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs, split):
+def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs):
     """lga_apply_pp on depth ranges long enough to reach its predicate-free steady body (several groups of pair steps), with
-    the body changes at every possible phase: one segment, two equal ones, and unequal splits; odd and even D."""
-    rng = np.random.default_rng(sum(shape) + segs + split)
+    the body changes at different phases: one, two and three segments; odd and even D."""
+    rng = np.random.default_rng(sum(shape) + segs)
     x = rng.standard_normal(shape).astype(np.float32)
     f = pc.l1norm(rng.standard_normal((shape[0], 75) + shape[2:]), 1)
     gy = rng.standard_normal(shape).astype(np.float32)
     y = port_oracle.lga_forward(x, f, 2)
     gx, gf = port_oracle.lga_backward(x, f, gy, 2)
-    sim.set_option("GANET_LGA_WAVE", 3)
+    sim.set_option("GANET_LGA_WAVE", 1)
     sim.set_option("GANET_LGA_SEGS", segs)
-    sim.set_option("GANET_LGA_SPLIT", split)
     try:
         err = pc.check_lga_chain(sim, DEV, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 3)
+        sim.set_option("GANET_LGA_WAVE", 1)
         sim.set_option("GANET_LGA_SEGS", 0)
-        sim.set_option("GANET_LGA_SPLIT", 1)
 
 
 @pytest.mark.parametrize("mode", ["guard_end", "guard_start", "late_reversed"])
 @pytest.mark.parametrize("shape", [(1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 1, 3, 34), (1, 2, 2, 2), (1, 26, 2, 6),
-                                   (1, 40, 3, 32), (1, 41, 7, 64), (1, 14, 9, 34)])
+                                   (1, 40, 3, 32), (1, 41, 7, 64), (1, 14, 9, 34), (3, 12, 4, 40), (4, 2, 2, 2), (3, 13, 4, 40)])
 def test_apply_on_pair_interleaved_volumes(sim, port_oracle, shape, mode):
     """ganet_lga_apply_paired (ABI v7): one pass and its data-backward with the input OR the output volume in the
     pair-interleaved layout (the private intermediate of an LGA2): equal to the oracle on the API layout, zero padding of the
-    last pair for odd D, depths on both sides of the steady body, border tiles, widths that are not a multiple of the tile."""
+    last pair for odd D, depths on both sides of the steady body, border tiles, widths that are not a multiple of the tile;
+    batches of three and four with an even D (the batch stride of an interleaved volume is ceil(D/2) pairs: ADVICE r2)."""
     B, D, H, W = shape
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
@@ -221,20 +189,18 @@ def test_apply_paired_argument_errors(sim):
 
 
 @pytest.mark.parametrize("mode", ["guard_end", "guard_start", "late_reversed"])
-@pytest.mark.parametrize("wps", [3, 2])
 @pytest.mark.parametrize("shape", [(1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 1, 3, 34), (1, 2, 2, 2), (1, 26, 2, 6),
-                                   (1, 40, 3, 32), (1, 41, 7, 64)])
-def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, wps, mode):
-    """ganet_lga_filter_grad_paired (ABI v7): gf of one pass with x in the pair-interleaved layout, write and accumulate
-    mode, both register budgets of the kernel."""
+                                   (1, 40, 3, 32), (1, 41, 7, 64), (3, 12, 4, 40), (4, 2, 2, 2)])
+def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, mode):
+    """ganet_lga_filter_grad_paired (ABI v7): gf of one pass with x (or gy) in the pair-interleaved layout, write and
+    accumulate mode; batches of three and four with an even D."""
     B, D, H, W = shape
-    rng = np.random.default_rng(sum(shape) + wps)
+    rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
     gy = rng.standard_normal(shape).astype(np.float32)
     f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
     _, want = port_oracle.lga_backward(x, f, gy, 2)
     dev = pc.NumpyDev("start" if mode == "guard_start" else "end")
-    sim.set_option("GANET_LGA_FG_WPS", wps)
     if mode == "late_reversed":
         sim.set_option("HIPSIM_LATE_DMA", 1)
         sim.set_option("HIPSIM_LANE_ORDER", 1)
@@ -251,14 +217,13 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, wps, mod
         sim.call("ganet_lga_filter_grad_paired", dev.ptr(dx), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, 0, 0, None)
         assert np.abs(gf - 2 * want).max() < 6e-5
     finally:
-        sim.set_option("GANET_LGA_FG_WPS", 3)
         sim.set_option("HIPSIM_LATE_DMA", 0)
         sim.set_option("HIPSIM_LANE_ORDER", 0)
 
 
-@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2)])
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2)])
 def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape):
-    """The call sequence of Lga2Function with GANET_LGA_PAIRED=1 (ganet_amd/functions/GANet.py: _LgaChain): forward
+    """The call sequence of Lga2Function (default; GANET_LGA_PAIRED=0 switches it off) (ganet_amd/functions/GANet.py: _LgaChain): forward
     x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 (interleaved) = gX(gy); gf += gF(x, g_t1); gx = gX(g_t1)."""
     B, D, H, W = shape
     rng = np.random.default_rng(sum(shape))
@@ -299,5 +264,5 @@ def test_mixed_item_list_of_the_plane_pair_apply(sim, port_oracle, shape, simds)
         err = pc.check_lga_chain(sim, pc.NumpyDev("start" if simds % 2 else "end"), x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_MIX", 0)
+        sim.set_option("GANET_LGA_MIX", 1)
         sim.set_option("HIPSIM_LATE_DMA", 0)
