@@ -54,9 +54,12 @@ class _OracleLga2(torch.autograd.Function):
         return torch.from_numpy(np.ascontiguousarray(gx)), torch.from_numpy(np.ascontiguousarray(gf)), None, None
 
 
-def dispagg_tail(x, lg1, lg2, maxdisp, ora, radius=2):
-    """models/GANet_deep.py:243-247 (x already upsampled and squeezed to [N,maxdisp+1,H,W])"""
+def dispagg_tail(x, lg1, lg2, maxdisp, ora, radius=2, parts=None):
+    """models/GANet_deep.py:243-247 (x already upsampled and squeezed to [N,maxdisp+1,H,W]).  `parts` (a dict) also receives
+    the volume in front of the final normalise + regression (the second LGA2's output), for tests of the fused tail."""
     x = _OracleLga2.apply(x, lga_filters(lg1), ora, radius)
     x = F.softmin(x, dim=1)
     x = _OracleLga2.apply(x, lga_filters(lg2), ora, radius)
+    if parts is not None:
+        parts["y2"] = x.detach()
     return norm_regression(x, maxdisp)

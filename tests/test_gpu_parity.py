@@ -464,3 +464,39 @@ def test_sga_wide_column_blocks_vs_oracle(api, dev, port_oracle, shape, mode):
     finally:
         api.set_option("GANET_SGA_WIDE_COL", 1)
     print("wide column blocks", shape, err)
+
+
+@pytest.mark.parametrize("N,C,H,W,maxdisp,Dr,Hr,Wr", [(1, 32, 128, 416, 64, 193, 384, 1248), (2, 32, 176, 320, 64, 193, 528, 960)])
+def test_cost_volume_and_regression_cfg3_cfg5_sizes(api, dev, port_oracle, N, C, H, W, maxdisp, Dr, Hr, Wr):
+    """GetCostVolume / DisparityRegression at the sizes of BASELINE configs 3 and 5: cost volumes [1,64,65,128,416] (886 MB)
+    and [2,64,65,176,320] (1.87 GB: element offsets beyond 2^31 bytes inside one tensor), regression on [1,193,384,1248] and
+    [2,193,528,960]; forward against the oracle (bit-exact copies / 1e-4), backward against the adjoint of the copies."""
+    rng = np.random.default_rng(N + H)
+    Dn = maxdisp + 1
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    y = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dx, dy = dev.to(x), dev.to(y)
+    cost = dev.empty((N, 2 * C, Dn, H, W))
+    api.call("ganet_cost_volume_forward", dx.data_ptr(), dy.data_ptr(), cost.data_ptr(), N, C, Dn, H, W, dev.stream)
+    want = port_oracle.cost_volume(x, y, maxdisp)
+    assert np.array_equal(dev.host(cost), want)
+    del want
+    # backward: a gradient volume of small integers makes every sum exact in fp32 (up to 65 terms) -- equality, not a tolerance
+    gc = dev.torch.randint(-3, 4, (N, 2 * C, Dn, H, W), device="cuda", generator=dev.torch.Generator(device="cuda").manual_seed(5)).float()
+    gx, gy = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+    api.call("ganet_cost_volume_backward", gc.data_ptr(), gx.data_ptr(), gy.data_ptr(), N, C, Dn, H, W, dev.stream)
+    wx, wy = dev.torch.zeros_like(gx), dev.torch.zeros_like(gy)
+    for i in range(Dn):                      # adjoint of the slice copies (modules/GANet.py:125-131), with torch on the device
+        wx[..., i:] += gc[:, :C, i, :, i:]
+        wy[..., :W - i] += gc[:, C:, i, :, i:]
+    assert dev.torch.equal(gx, wx) and dev.torch.equal(gy, wy)
+    del gc, cost, wx, wy
+    p = rng.random((N, Dr, Hr, Wr)).astype(np.float32)
+    p /= p.sum(1, keepdims=True)
+    out = dev.empty((N, Hr, Wr))
+    api.call("ganet_disparity_regression_forward", dev.to(p).data_ptr(), out.data_ptr(), N, Dr, Hr, Wr, dev.stream)
+    np.testing.assert_allclose(dev.host(out), port_oracle.disparity_regression(p, Dr - 1), rtol=1e-5, atol=1e-4)
+    go = rng.standard_normal((N, Hr, Wr)).astype(np.float32)
+    gp = dev.empty(p.shape)
+    api.call("ganet_disparity_regression_backward", dev.to(go).data_ptr(), gp.data_ptr(), N, Dr, Hr, Wr, dev.stream)
+    assert np.array_equal(dev.host(gp), go[:, None] * np.arange(Dr, dtype=np.float32)[None, :, None, None])
