@@ -242,31 +242,26 @@ int ganet_selftest_dpp(int *scratch_dev, int *host_out, void *stream);
  * maximum and sum); scratch / host_out: >= 4*64 ints. */
 int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
 
-/* Tuning knobs (also read from the environment at first use):
- *   GANET_SGA_GD_V / GANET_SGA_GD_H = 4|8|16  lanes per scanline, vertical / horizontal scans
- *                         (defaults 4 / 16; GANET_SGA_GD sets both through ganet_set_option)
- *   GANET_SGA_STREAMS=0|1 one side stream per direction (default 0: measured slower)
+/* Knobs (also read from the environment at first use).  One default path per operator plus its general fallback; the knobs
+ * exist so that tests can reach the fallbacks and the forced modes:
+ *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: the 16-lane
+ *                         segment kernels, which are also the fallback for W % 4 != 0 and D > 208)
  *   GANET_SGA_WIDE_SCAN=0|1|2  scans with the whole wavefront on one scanline: never | for inputs with few scanlines and for
- *                         D > 272 (default) | whenever D > 48
- *   GANET_LGA_MIX=0|1     plane-pair forward / data-backward with a MIXED item list: whole tiles first (a whole number per
- *                         SIMD), the remaining tiles cut into depth segments, at most one segment per SIMD -- the waves of a
- *                         SIMD share one VALU, so a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average
- *                         at 240x624).  Default 0: checked on the CPU emulator, not yet measured on a GPU
- *   GANET_LGA_PAIRED=0|1  (read by ganet_amd.functions.GANet, not by this library) Lga2Function keeps its intermediate volume
- *                         pair-interleaved (ganet_lga_apply_paired).  Default 0: checked on the CPU emulator, not yet measured
- *                         on a GPU (scripts/check_lga_paired.py)
- *   GANET_SGA_WIDE_COL=0|1  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
- *                         D <= 192; for inputs with few column blocks).  Default 0: checked on the CPU emulator, not yet
- *                         measured on a GPU (scripts/check_wide_col.py)
- *   GANET_SGA_BLOCK_V / GANET_SGA_BLOCK_H  threads per block, vertical / horizontal scans (segment kernels)
- *   GANET_SGA_ROWWAVE / GANET_SGA_COLBLOCK = 0|1  LDS-staged row-per-wave / column-block scans (default 1; 0: segment kernels)
- *   GANET_SGA_MERGE4 = 0|1  four-pixels-per-lane merge + arg-max (default 1)
- *   GANET_SGA_POINT_BLOCK = 64|128|256  threads per block of the per-pixel gradient kernel (default 256)
- *   GANET_LGA_WAVE = 0|1|2|3  LGA kernels: 256-thread tiles | wave-autonomous, register staging | wave-autonomous, LDS-DMA,
- *                         FMAs packed along window columns | wave-autonomous, LDS-DMA, FMAs packed along plane pairs (default 3)
- *   GANET_LGA_FG_WPS = 2|3  plane-pair filter gradient: register budget for 2 or 3 waves per SIMD (default 3)
- *   GANET_LGA_VMCNT_SAFE = 0|1  lga_apply_dma (GANET_LGA_WAVE=2): never count result stores in the wait for a staged plane
- *   GANET_LGA_SEGS = n      depth segments per tile for the wave-autonomous LGA kernels (0 = automatic) */
+ *                         D > 272 (default) | whenever D > 48 (tests).  D up to 1088
+ *   GANET_SGA_WIDE_COL=0|1|2  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
+ *                         D <= 192): never | for inputs with few column blocks and D >= 96 (default; measured on
+ *                         [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40) | whenever the kernel applies (tests)
+ *   GANET_LGA_WAVE = 0|1  LGA kernels: 256-thread tiles (any radius; the fallback) | wave-autonomous, LDS-DMA, FMAs packed
+ *                         along plane pairs (radius <= 2; default)
+ *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
+ *   GANET_LGA_MIX=0|1|n   the same kernels with a MIXED item list: whole tiles first (a whole number per SIMD), the remaining
+ *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so
+ *                         a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average at 240x624).  Default 1
+ *                         (measured: forward pass 0.103 -> 0.0955 ms); n > 1: n SIMDs assumed (tests)
+ * Read by ganet_amd.functions.GANet, not by this library: GANET_LGA_PAIRED=0 keeps the intermediate volume of a two-pass
+ * chain in the API layout instead of pair-interleaved (ganet_lga_apply_paired; default on, measured -7 % on Lga2Function
+ * fwd+bwd); GANET_SGA_SAVE=recompute selects the reference's memory profile.  GANET_TRACE_DISPATCH=1 prints which LGA kernel
+ * a call took.  Unknown names -> GANET_E_INVALID. */
 int ganet_set_option(const char *name, int value);
 
 #ifdef __cplusplus
