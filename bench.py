@@ -377,8 +377,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="also time the step with its SGA and LGA halves on two streams (extra field, not `value`)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="skip the extra measurement of the step with its SGA and LGA halves on two streams "
+                         "(`two_stream_ms_per_step`: an extra field, never `value`)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

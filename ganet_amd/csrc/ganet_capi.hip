@@ -505,10 +505,52 @@ int device_cus()
 }
 
 // ---- LGA dispatch -------------------------------------------------------------------
-// Work items of the plane-pair forward / data-backward = tiles x depth segments.  Every item re-gathers its pixels' filter
-// taps (75 loads per lane; for the data-backward from 25 neighbouring pixels) and fills its ring, 0.038 ms of a 0.107 ms pass
-// (profiles/r2f_lga_pp_ablation.txt), so ONE segment per tile is best (profiles/r2e_ab_lga_plane_pairs_v2.txt) unless there are
-// too few tiles to fill the wave slots; segments start on even planes (32-bit byte offsets inside a plane pair).
+// Work items of the plane-pair forward / data-backward (LgaSegMix).  Every item re-gathers its pixels' filter taps (75 loads per
+// lane; for the data-backward from 25 neighbouring pixels) and fills its ring, 0.038 ms of a 0.107 ms pass
+// (profiles/r2f_lga_pp_ablation.txt), so whole tiles are best (profiles/r2e_ab_lga_plane_pairs_v2.txt) unless there are too few
+// of them to fill the wave slots; with a whole number q < 3 of tiles per SIMD plus a remainder, the remainder is cut into
+// segments, at most one per SIMD (the mixed list).  `whole_only`: the pass carries a per-pixel reduction over all of D.
+LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items)
+{
+  LgaSegMix mx;
+  mx.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+  mx.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+  const i64 tiles = (i64)mx.tiles_x * mx.tiles_y * B;
+  mx.n_whole = (int)(tiles < (1ll << 30) ? tiles : (1ll << 30));
+  mx.nsub = 1;
+  mx.sub_len = (D + 1) & ~1;
+  *items = tiles;
+  if (whole_only || tiles >= (1ll << 30)) return mx;
+  const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
+  int nseg = opts().lga_segs;
+  if (nseg <= 0) {
+    nseg = tiles * 2 > slots ? 1 : (int)((slots + tiles - 1) / tiles);
+    if (nseg > D / 16) nseg = D / 16 > 1 ? D / 16 : 1;
+  }
+  if (nseg > D) nseg = D;
+  if (nseg > 1) {                                   // every tile cut into equal segments
+    mx.n_whole = 0;
+    mx.sub_len = ((D + nseg - 1) / nseg + 1) & ~1;
+    mx.nsub = (D + mx.sub_len - 1) / mx.sub_len;
+    *items = tiles * mx.nsub;
+    return mx;
+  }
+  const int mixo = opts().lga_mix;
+  const i64 S = mixo > 1 ? (i64)mixo : (i64)4 * device_cus();
+  if (mixo && opts().lga_segs <= 0 && tiles / S < LGA_WAVES_PER_SIMD && tiles % S != 0) {
+    const i64 r = tiles % S;
+    int nsub = (int)(S / r);
+    if (nsub > D / 16) nsub = D / 16;
+    if (nsub >= 2) {
+      mx.n_whole = (int)(tiles - r);
+      mx.sub_len = ((D + nsub - 1) / nsub + 1) & ~1;
+      mx.nsub = (D + mx.sub_len - 1) / mx.sub_len;
+      *items = mx.n_whole + r * mx.nsub;
+    }
+  }
+  return mx;
+}
+
 template <int R>
 int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H, int W,
                    bool transposed, hipStream_t st)
@@ -517,47 +559,13 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   if constexpr (R <= 2) {
     if (opts().lga_wave && (i64)H * W < (1ll << 28)) {
-      LgaSeg sg;
-      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      const i64 tiles = (i64)sg.tiles_x * sg.tiles_y * B;
-      const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
-      sg.nseg = opts().lga_segs;
-      if (sg.nseg <= 0) {
-        sg.nseg = tiles * 2 > slots ? 1 : (int)((slots + tiles - 1) / tiles);
-        if (sg.nseg > D / 16) sg.nseg = D / 16 > 1 ? D / 16 : 1;
-      }
-      if (sg.nseg > D) sg.nseg = D;
-      sg.seg_len = ((D + sg.nseg - 1) / sg.nseg + 1) & ~1;
-      sg.nseg = (D + sg.seg_len - 1) / sg.seg_len;
-      static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
-      if constexpr (R == 2) {
-        // mixed item list (LgaSegMix): q whole tiles per SIMD + at most one segment of the remaining ones
-        const int mixo = opts().lga_mix;
-        const i64 S = mixo > 1 ? (i64)mixo : (i64)4 * device_cus();
-        if (mixo && opts().lga_segs <= 0 && tiles < (1ll << 30) && tiles / S < LGA_WAVES_PER_SIMD && tiles % S != 0) {
-          const i64 r = tiles % S;
-          int nsub = (int)(S / r);
-          if (nsub > D / 16) nsub = D / 16;
-          if (nsub >= 2) {
-            LgaSegMix mx;
-            mx.tiles_x = sg.tiles_x; mx.tiles_y = sg.tiles_y;
-            mx.n_whole = (int)(tiles - r);
-            mx.sub_len = ((D + nsub - 1) / nsub + 1) & ~1;
-            mx.nsub = (D + mx.sub_len - 1) / mx.sub_len;
-            const i64 items_mx = mx.n_whole + r * mx.nsub;
-            if (transposed) GA_LAUNCH((lga_apply_pp_mix<R, true>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
-            else GA_LAUNCH((lga_apply_pp_mix<R, false>), dim3((unsigned)items_mx), dim3(64), st, x, f, y, geo, mx);
-            if (trace) fprintf(stderr, "[ganet] lga_apply_pp_mix T=%d whole=%d + %lld x %d segments of %d planes\n", (int)transposed, mx.n_whole, (long long)r, mx.nsub, mx.sub_len);
-            return check_launch("lga apply (plane pairs, mixed item list)");
-          }
-        }
-      }
-      const i64 items_pp = tiles * sg.nseg;
-      if (items_pp < (1ll << 31)) {
-        if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items_pp), dim3(64), st, x, f, y, geo, sg);
-        if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld nseg=%d\n", R, (int)transposed, (long long)items_pp, sg.nseg);
+      i64 items;
+      const LgaSegMix mx = lga_items(W, H, B, D, false, &items);
+      if (items < (1ll << 31)) {
+        if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
+        else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
+        static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
+        if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld: %d whole tiles + segments of %d planes x %d\n", R, (int)transposed, (long long)items, mx.n_whole, mx.sub_len, mx.nsub);
         return check_launch("lga apply (plane pairs)");
       }
     }
@@ -576,11 +584,8 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
     return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: needs W even, planes below 2^28 pixels and 16-byte aligned volumes");
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  LgaSeg sg;
-  sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-  sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-  sg.nseg = 1; sg.seg_len = (D + 1) & ~1;
-  const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+  i64 items;
+  const LgaSegMix sg = lga_items(W, H, B, D, false, &items);
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: too many tiles");
   if (x_paired) {
     if (transposed) GA_LAUNCH((lga_apply_pp_pi<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
@@ -619,11 +624,8 @@ int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snor
     if ((i64)H * W < (1ll << 28)) {
       LgaGeom geo;
       geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-      LgaSeg sg;
-      sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-      sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-      sg.nseg = 1; sg.seg_len = (D + 1) & ~1;
-      const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+      i64 items;
+      const LgaSegMix sg = lga_items(W, H, B, D, true, &items);      // (the epilogue reduces over all of D: whole tiles only)
       if (items < (1ll << 31)) {
         GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
         return check_launch("lga apply + regression epilogue (plane pairs)");

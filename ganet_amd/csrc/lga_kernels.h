@@ -552,32 +552,15 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #endif
 }
 
-// ---- lga_apply_pp (API layout in, API layout out) and its pair-interleaved forms: lga_apply_pp.inc --------------------------
-#define GA_PP_NAME lga_apply_pp
-#define GA_PP_SEG_T LgaSeg
-#define GA_PP_DECODE lga_decode_item
-#define GA_PP_IN 0
-#define GA_PP_OUT 0
-#define GA_PP_SLOT PC::SLOT
-#define GA_PP_NDC ND
-#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
-#include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
-
-// ---- MIXED item list: most tiles whole, the rest cut into depth segments -----------------------------------------------------
+// ---- item list of the forward / data-backward kernels: whole tiles first, then tiles cut into depth segments -----------------
 // These kernels are bound by VALU issue and the waves of a SIMD share one VALU, so a pass lasts as long as the SIMD with the
 // most resident work: 2,400 tiles on 1,024 SIMDs are 2 or 3 tiles per SIMD and the pass takes the time of 3 (the FMA-only
 // ablation runs exactly 3 x 97 x 75 packed FMAs x 4 clk = 36 us), although the average is 2.34.  Cutting EVERY tile in
 // two was measured slower (each item gathers its 75 taps and fills its pipeline again).  Here only the T mod S tiles
 // beyond a whole number per SIMD are cut, into nsub segments with T mod S x nsub <= S: items [0, n_whole) are whole tiles --
-// dispatched first, q per SIMD -- and the rest are the segments, at most one per SIMD.
+// dispatched first, q per SIMD -- and the rest are the segments, at most one per SIMD (measured: forward pass 0.103 ->
+// 0.0955 ms, profiles/r3a_*).  The same list describes the plain forms: n_whole = all tiles (nothing cut), or n_whole = 0 with
+// every tile cut into nsub equal segments (few tiles; GANET_LGA_SEGS).  Segments start on even planes.
 struct LgaSegMix {
   int tiles_x, tiles_y;
   int n_whole;        // whole tiles (items [0, n_whole)), then nsub items per remaining tile
@@ -601,7 +584,8 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
   by = item % sg.tiles_y;
   b = item / sg.tiles_y;
 }
-#define GA_PP_NAME lga_apply_pp_mix
+// ---- lga_apply_pp (API layout in, API layout out) and its pair-interleaved forms: lga_apply_pp.inc --------------------------
+#define GA_PP_NAME lga_apply_pp
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
 #define GA_PP_IN 0
@@ -622,8 +606,8 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
 // API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
 #define GA_PP_NAME lga_apply_pp_po
-#define GA_PP_SEG_T LgaSeg
-#define GA_PP_DECODE lga_decode_item
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
 #define GA_PP_IN 0
 #define GA_PP_OUT 1
 #define GA_PP_SLOT PC::SLOT
@@ -640,8 +624,8 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #undef GA_PP_Y
 // pair-interleaved in, API layout out (second pass of an LGA2; data-backward of its first pass)
 #define GA_PP_NAME lga_apply_pp_pi
-#define GA_PP_SEG_T LgaSeg
-#define GA_PP_DECODE lga_decode_item
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
 #define GA_PP_IN 1
 #define GA_PP_OUT 0
 #define GA_PP_SLOT 512

@@ -5,7 +5,7 @@ import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = ["lga_apply_dma", "lga_filter_grad_dma", "lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp_mix", "lga_apply_pp", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gyp", "lga_filter_grad_pp"]
+KERNELS = ["lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gyp", "lga_filter_grad_pp"]
 
 
 def asm_text(path=None):

@@ -84,7 +84,7 @@ def test_sga_shapes_guarded(sim, port_oracle, shape, guard):
 # as the kernel's own waits permit; a thread that ends with copies in flight aborts).  A count that is one too loose, a wait
 # placed behind the first read of a slot, or a missing final wait gives wrong results / an abort HERE instead of a
 # timing-dependent stale read on the GPU ("the emulator compiles GA_VMCNT to a no-op").
-@pytest.mark.parametrize("segs,mix,paired", [(0, 0, 0), (2, 0, 0), (3, 0, 0), (0, 2, 0), (0, 0, 1)])
+@pytest.mark.parametrize("segs,mix,paired", [(0, 0, 0), (2, 0, 0), (3, 0, 0), (0, 2, 0), (0, 0, 1), (0, 3, 1), (2, 0, 1)])
 def test_lga_counted_waits_with_late_landing_copies(sim, port_oracle, segs, mix, paired):
     dev = pc.NumpyDev()
     sim.set_option("GANET_LGA_SEGS", segs)

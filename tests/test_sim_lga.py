@@ -221,8 +221,9 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, mode):
         sim.set_option("HIPSIM_LANE_ORDER", 0)
 
 
-@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2)])
-def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape):
+@pytest.mark.parametrize("mix", [1, 3, 0])
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2), (1, 47, 2, 100)])
+def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape, mix):
     """The call sequence of Lga2Function (default; GANET_LGA_PAIRED=0 switches it off) (ganet_amd/functions/GANet.py: _LgaChain): forward
     x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 (interleaved) = gX(gy); gf += gF(x, g_t1); gx = gX(g_t1)."""
     B, D, H, W = shape
@@ -233,6 +234,14 @@ def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, sha
     y_want, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
     gx_want, gf_want = port_oracle.lga_chain_backward(ins, f, gy, 2)
     dev = DEV
+    sim.set_option("GANET_LGA_MIX", mix)          # item lists of the interleaved kernels: default / three SIMDs assumed / whole tiles
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        err = pc.check_lga2_paired(sim, pc.NumpyDev("start" if mix == 3 else "end"), x, f, gy, 2, 2, {"y": y_want, "gx": gx_want, "gf": gf_want})
+        assert max(err.values()) < 5e-5, err
+    finally:
+        sim.set_option("GANET_LGA_MIX", 1)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
     dx, df, dgy = dev.to(x), dev.to(f), dev.to(gy)
     t1p, y = dev.empty((B, (D + 1) // 2, H, W, 2)), dev.empty(shape)
     sim.call("ganet_lga_apply_paired", dev.ptr(dx), dev.ptr(df), dev.ptr(t1p), B, D, H, W, 2, 0, 0, 1, None)
