@@ -475,6 +475,19 @@ def main():
                 one_step(inp)
             torch.cuda.synchronize()
             line["eager_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
+        # the contract's extra objects first; a failure in one of them must not cost the line its measured value
+        if not args.no_roofline:
+            try:
+                stages = stage_timings(inp)
+                line["roofline"] = roofline_from_stages(stages)
+                line["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
+            except Exception as e:            # noqa: BLE001
+                line["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_cpu_baseline and ctx.world_size == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:            # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if args.overlap:
             # informational: SGA half and LGA half of the step on two streams (memory-bound scans beside VALU-bound LGA)
             try:
@@ -499,12 +512,6 @@ def main():
                 line["two_stream_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
             except Exception as e:
                 line["two_stream_ms_per_step"] = f"failed: {type(e).__name__}: {e}"
-        if not args.no_roofline:
-            stages = stage_timings(inp)
-            line["roofline"] = roofline_from_stages(stages)
-            line["stage_ms"] = {k: round(v, 4) for k, v in stages.items()}
-        if not args.no_cpu_baseline and ctx.world_size == 1:
-            line["cpu_baseline"] = cpu_baseline()
     if ctx.world_size > 1:
         # The gradient all-reduce of a data-parallel caller (26.3 MB fp32 = GANet-deep's parameters) over RCCL / xGMI, AFTER
         # the timed region and on every rank; an extra object, never part of `value` (the op metric has no collective).

@@ -6,6 +6,7 @@ data-path collective: each rank owns whole samples.  What is collective is only 
 protocol of bench.py (barrier + max-over-ranks) and (b), for training callers, the parameter
 gradient all-reduce, for which `all_reduce_mean_` below is the bucketed RCCL form
 (backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests)."""
+import datetime
 import os
 import time
 from dataclasses import dataclass
@@ -119,7 +120,8 @@ def allreduce_probe(ctx, backend, device, nelem=GRAD_ELEMS_GANET_DEEP, iters=10,
     if ctx.world_size == 1:
         return None
     try:
-        group = dist.new_group(backend=backend) if dist.get_backend() != backend else None
+        # (a bounded wait: a collective that cannot complete becomes an error string after a minute, not a hung benchmark)
+        group = dist.new_group(backend=backend, timeout=datetime.timedelta(seconds=60)) if dist.get_backend() != backend else None
         g = torch.ones(nelem, dtype=torch.float32, device=device) * (ctx.rank + 1)
 
         def once():
