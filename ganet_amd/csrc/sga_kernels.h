@@ -791,12 +791,4 @@ sga_merge_running(const float *__restrict__ tmp, float *__restrict__ out, MaskT 
   }
 }
 
-// float-valued mask (reference layout) -> uint8
-static __global__ void __launch_bounds__(256)
-mask_f32_to_u8(const float *__restrict__ m, uint8_t *__restrict__ o, i64 n)
-{
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = (uint8_t)(int)m[i];
-}
-
 }  // namespace ga
