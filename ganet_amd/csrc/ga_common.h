@@ -81,6 +81,63 @@ GA_DEV f2 lds_read_b64(lds_cptr p)
 }
 #endif
 
+// Result stores of the streaming kernels -- directional / adjoint volumes, merged output and mask, the final outputs of an
+// LGA2 chain: written once, read much later or not at all -- are NON-TEMPORAL (`global_store ... nt`), and so are the loads of
+// volumes nothing reads again soon (the directional volumes in the merge; they and the adjoint volumes in the per-pixel
+// gradient kernel): they stream past the L2 / Infinity Cache instead of displacing what the kernels around them re-read (x,
+// gradOut and the mask are read by four scans each, the filter taps by every LGA pass, an interleaved intermediate by the very
+// next kernel).  Measured on seven boxes, whole step, same-box A/B (profiles/r3l_*, r3m_*): -4.1 % on the last two (1.797 ->
+// 1.719 ms; the scans' and the merge's stores -1.4 ... -3.0 %, the per-pixel kernel's loads up to -2.5 %, the LGA2 outputs -2.0 %,
+// the merge's loads -0.4 %).  NOT for the per-pixel kernel's own gradX store (+1 %), every LGA output (an intermediate is
+// re-read at once: ambiguous), the scans' loads (neutral), the LGA tap gather (+3 %: the taps are re-read by the next pass).  Bit masks for A/B builds (scripts/build_variants.py, -DGA_NT_STORES=n -DGA_NT_LOADS=n):
+//   stores: 1 column scans, 2 row scans, 4 merge, 8 per-pixel gradients, 16 LGA apply, 32 LGA filter gradient, 64 LGA apply from an
+//           interleaved input only (the final outputs of an LGA2 chain, not its intermediates)
+//   loads:  1 merge, 2 per-pixel gradients' G / A, 4 scan inputs, 8 per-pixel gradients' x, 16 LGA filter taps
+#ifndef GA_NT_STORES
+#define GA_NT_STORES 71
+#endif
+#ifndef GA_NT_LOADS
+#define GA_NT_LOADS 3
+#endif
+typedef float ga_f4v __attribute__((ext_vector_type(4)));
+template <bool ON, typename T> GA_DEV void stream_store(T *p, const T &v)
+{
+#if !defined(GA_HIPSIM)
+  if constexpr (ON) { __builtin_nontemporal_store(v, p); return; }
+#endif
+  *p = v;
+}
+template <bool ON> GA_DEV void stream_store(f4 *p, const f4 &v)      // (the builtin wants a native vector type, not HIP's float4 class)
+{
+#if !defined(GA_HIPSIM)
+  if constexpr (ON) {
+    ga_f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<ga_f4v *>(p));
+    return;
+  }
+#endif
+  *p = v;
+}
+
+template <bool ON, typename T> GA_DEV T stream_load(const T *p)
+{
+#if !defined(GA_HIPSIM)
+  if constexpr (ON) return __builtin_nontemporal_load(p);
+#endif
+  return *p;
+}
+template <bool ON> GA_DEV f4 stream_load(const f4 *p)
+{
+#if !defined(GA_HIPSIM)
+  if constexpr (ON) {
+    const ga_f4v t = __builtin_nontemporal_load(reinterpret_cast<const ga_f4v *>(p));
+    f4 o; o.x = t.x; o.y = t.y; o.z = t.z; o.w = t.w;
+    return o;
+  }
+#endif
+  return *p;
+}
+
 GA_DEV float f4_get(const f4 &v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 GA_DEV void f4_set(f4 &v, int k, float a)
 {

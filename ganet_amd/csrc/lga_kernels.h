@@ -510,13 +510,13 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
       ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
     }
     float own = 0.f;
-    if (CHECK || !TRANSPOSED || dd != 1) own = (fb + (i64)t * geo.HW)[pix32];   // interior gX needs own taps only for the d-edge sums
+    if (CHECK || !TRANSPOSED || dd != 1) own = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)t * geo.HW + pix32);   // interior gX needs own taps only for the d-edge sums
     float wv = own;
     if (TRANSPOSED) {
       // unconditional load, value masked below (a load under a condition costs an s_waitcnt vmcnt(0) each)
       const int tf = (2 - dd) * K + (-a + R) * WS + (-bb + R);
       const int noff = ok ? a * geo.W + bb : 0;
-      wv = (fb + (i64)tf * geo.HW)[(unsigned)((int)pix32 + noff)];
+      wv = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)tf * geo.HW + (unsigned)((int)pix32 + noff));
     }
     const int okm = ok ? -1 : 0;
     cmid += i2f(f2i(own) & ~okm);

@@ -542,12 +542,12 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
         const int d = dc + u;
         const i64 o = vb + (i64)(d < D ? d : D - 1) * HW;
         const i64 on = vb + (i64)(d + 1 < D ? d + 1 : D - 1) * HW;
-        xv[u] = x[o];
+        xv[u] = stream_load<(GA_NT_LOADS & 8) != 0>(x + o);
         gxv[u] = ACC ? gradX[o] : 0.f;
 #pragma unroll
         for (int q = 0; q < NDIR; q++) {
-          Gv[u][q] = pa.G[q][o];
-          Av[u][q] = pa.A[q][on + poff[q]];                          // A[pp][d+1] (used only where d + 1 < D)
+          Gv[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.G[q] + o);
+          Av[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + on + poff[q]);                          // A[pp][d+1] (used only where d + 1 < D)
         }
       }
 #pragma unroll
@@ -571,7 +571,7 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
             a_m[q] = a_0[q];
             a_0[q] = a_p;
           }
-          gradX[vb + (i64)d * HW] = gacc;
+          stream_store<(GA_NT_STORES & 8) != 0>(gradX + vb + (i64)d * HW, gacc);
         }
       }
     }
@@ -661,10 +661,10 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
       for (int u = 0; u < DU; u++) {
         const int d = dc + u < D ? dc + u : D - 1;
         const i64 o = vb + (i64)d * HW;
-        a[u][0] = *reinterpret_cast<const f4 *>(A0 + o);
-        a[u][1] = *reinterpret_cast<const f4 *>(A1 + o);
-        a[u][2] = *reinterpret_cast<const f4 *>(A2 + o);
-        a[u][3] = *reinterpret_cast<const f4 *>(A3 + o);
+        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o));
+        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o));
+        a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
+        a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
       }
 #pragma unroll
       for (int u = 0; u < DU; u++) {
@@ -688,8 +688,8 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
           const i64 o = vb + (i64)d * HW;
           f4 r;
           r.x = ov[0]; r.y = ov[1]; r.z = ov[2]; r.w = ov[3];
-          *reinterpret_cast<f4 *>(out + o) = r;
-          *reinterpret_cast<unsigned *>(mask + o) = mk;
+          stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<f4 *>(out + o), r);
+          stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<unsigned *>(mask + o), mk);
 #pragma unroll
           for (int q = 0; q < 4; q++)
 #pragma unroll

@@ -124,7 +124,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
       for (int n = 0; n < NPC; n++) {
         int pl = n * C::PPI + psub;
         pl = pl < D ? pl : D - 1;
-        const f4 t = *reinterpret_cast<const f4 *>(xb + (i64)pl * geo.HW);
+        const f4 t = stream_load<(GA_NT_LOADS & 4) != 0>(reinterpret_cast<const f4 *>(xb + (i64)pl * geo.HW));
         xpre[q][n][0] = t.x; xpre[q][n][1] = t.y; xpre[q][n][2] = t.z; xpre[q][n][3] = t.w;
       }
       const f4 t = *reinterpret_cast<const f4 *>(g + gbo[q] + (i64)(psub < 5 ? psub : 4) * geo.HW + wq);
@@ -210,8 +210,10 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
               v.x = fmaxf(fmaf(v.x, bn_sc[q], bn_sh[q]), 0.f); v.y = fmaxf(fmaf(v.y, bn_sc[q], bn_sh[q]), 0.f);
               v.z = fmaxf(fmaf(v.z, bn_sc[q], bn_sh[q]), 0.f); v.w = fmaxf(fmaf(v.w, bn_sc[q], bn_sh[q]), 0.f);
             }
+            *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) = v;      // (read back by the next direction's scan: a plain store)
+          } else {
+            stream_store<(GA_NT_STORES & 2) != 0>(reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq), v);
           }
-          *reinterpret_cast<f4 *>(Ab + (i64)pl * geo.HW + wq) = v;
         }
       }
     }
@@ -290,7 +292,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
         int pl = n * C::PPI + psub;
         pl = pl < D ? pl : D - 1;
         const i64 o = vb[q] + (i64)pl * geo.HW + wq;
-        const f4 t = *reinterpret_cast<const f4 *>(gout + o);
+        const f4 t = stream_load<(GA_NT_LOADS & 4) != 0>(reinterpret_cast<const f4 *>(gout + o));
         gpre[q][n][0] = t.x; gpre[q][n][1] = t.y; gpre[q][n][2] = t.z; gpre[q][n][3] = t.w;
         mpre[q][n] = *reinterpret_cast<const uint32_t *>(mask + o);
       }
@@ -382,8 +384,8 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       for (int p0 = 0; p0 < D; p0 += C::PPI) {
         const int pl = p0 + psub;
         if (pl < D && col_ok && rok[q])
-          *reinterpret_cast<f4 *>(G + vb[q] + (i64)pl * geo.HW + wq) =
-              *reinterpret_cast<const f4 *>(gt + q * TS + pl * C::RS + 4 * piece);
+          stream_store<(GA_NT_STORES & 2) != 0>(reinterpret_cast<f4 *>(G + vb[q] + (i64)pl * geo.HW + wq),
+                       *reinterpret_cast<const f4 *>(gt + q * TS + pl * C::RS + 4 * piece));
       }
     }
     GA_WAVE_SYNC();   // the workgroup is one wavefront: its LDS queue is in order, nothing to drain

@@ -1,0 +1,40 @@
+"""Same-box A/B of the WHOLE benchmark step (bench.one_step captured into a hipGraph, replayed) for several builds of the library
+(scripts/build_variants.py):  python scripts/ab_step.py libA.so libB.so ...   -> ms per step per library, interleaved repetitions"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ganet_amd import _native
+
+dev = torch.device("cuda:0")
+graphs = {}
+for name in sys.argv[1:]:
+    _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
+    inp = bench.make_inputs(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            bench.one_step(inp)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = bench.one_step(inp)
+    graphs[name] = (g, inp, keep)
+res = {n: [] for n in graphs}
+for rep in range(5):
+    for name, (g, _, _) in graphs.items():
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            g.replay()
+        e1.record(); e1.synchronize()
+        res[name].append(e0.elapsed_time(e1) / 50)
+for name, v in res.items():
+    v = sorted(v)
+    print(f"{name:32s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f}  max {v[-1]:.4f}", flush=True)
