@@ -90,11 +90,11 @@ GA_DEV f2 lds_read_b64(lds_cptr p)
 // 1.719 ms; the scans' and the merge's stores -1.4 ... -3.0 %, the per-pixel kernel's loads up to -2.5 %, the LGA2 outputs -2.0 %,
 // the merge's loads -0.4 %).  NOT for the per-pixel kernel's own gradX store (+1 %), every LGA output (an intermediate is
 // re-read at once: ambiguous), the scans' loads (neutral), the LGA tap gather (+3 %: the taps are re-read by the next pass).  Bit masks for A/B builds (scripts/build_variants.py, -DGA_NT_STORES=n -DGA_NT_LOADS=n):
-//   stores: 1 column scans, 2 row scans, 4 merge, 8 per-pixel gradients, 16 LGA apply, 32 LGA filter gradient, 64 LGA apply from an
+//   stores: 1 column scans, 2 row scans, 4 merge (output volume), 128 merge (direction mask), 8 per-pixel gradients, 16 LGA apply, 32 LGA filter gradient, 64 LGA apply from an
 //           interleaved input only (the final outputs of an LGA2 chain, not its intermediates)
 //   loads:  1 merge, 2 per-pixel gradients' G / A, 4 scan inputs, 8 per-pixel gradients' x, 16 LGA filter taps
 #ifndef GA_NT_STORES
-#define GA_NT_STORES 71
+#define GA_NT_STORES 199
 #endif
 #ifndef GA_NT_LOADS
 #define GA_NT_LOADS 3

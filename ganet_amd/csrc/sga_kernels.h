@@ -689,7 +689,7 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
           f4 r;
           r.x = ov[0]; r.y = ov[1]; r.z = ov[2]; r.w = ov[3];
           stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<f4 *>(out + o), r);
-          stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<unsigned *>(mask + o), mk);
+          stream_store<(GA_NT_STORES & 128) != 0>(reinterpret_cast<unsigned *>(mask + o), mk);
 #pragma unroll
           for (int q = 0; q < 4; q++)
 #pragma unroll
