@@ -104,7 +104,7 @@ def run(args, hook=None):
             "grad_allreduce": "DistributedDataParallel (RCCL)" if ctx.world_size > 1 and not cpu else
                               ("DistributedDataParallel (gloo)" if ctx.world_size > 1 else "none (1 rank)"),
             "peak_mem_GB": None if cpu else round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
-            "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)], "dtype": "f32",
+            "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)] if losses else None, "dtype": "f32",
             "data": "synthetic", "weights": "random init" if not args.resume else args.resume, "kernel_share": share}
     gdist.finish(ctx)
     if ctx.rank == 0:
