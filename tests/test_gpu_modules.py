@@ -42,9 +42,13 @@ def test_sga_module_autograd(torch_mod, port_oracle, monkeypatch, save_mode):
         assert np.abs(_np(t.grad) - want).max() <= pc.TOL
 
 
-@pytest.mark.parametrize("cls_name,passes,five_d", [("LGA", 1, False), ("LGA2", 2, False), ("LGA3", 3, False),
-                                                    ("LGA3D", 1, True), ("LGA3D2", 2, True), ("LGA3D3", 3, True)])
-def test_lga_modules_autograd(torch_mod, port_oracle, cls_name, passes, five_d):
+@pytest.mark.parametrize("cls_name,passes,five_d,paired", [("LGA", 1, False, "1"), ("LGA2", 2, False, "1"), ("LGA2", 2, False, "0"),
+                                                           ("LGA3", 3, False, "1"), ("LGA3D", 1, True, "1"), ("LGA3D2", 2, True, "1"),
+                                                           ("LGA3D2", 2, True, "0"), ("LGA3D3", 3, True, "1")])
+def test_lga_modules_autograd(torch_mod, port_oracle, monkeypatch, cls_name, passes, five_d, paired):
+    """every LGA module through autograd; the two-pass forms both with the pair-interleaved private intermediate (default) and
+    with GANET_LGA_PAIRED=0 (intermediate in the API layout)"""
+    monkeypatch.setenv("GANET_LGA_PAIRED", paired)
     torch = torch_mod
     import torch.nn.functional as F
     import ganet_amd.modules.GANet as M
