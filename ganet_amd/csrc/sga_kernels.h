@@ -635,7 +635,7 @@ sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const f
 // of 16-byte requests reaches ~6.3 TB/s on this chip (scripts/ubench/mall_probe.py).
 // Needs HW % 4 == 0 and 16-byte aligned volumes (launcher checks).
 #ifndef GA_MERGE_DU
-#define GA_MERGE_DU 1
+#define GA_MERGE_DU 2      // planes of loads in flight per lane: 1 was best with plain loads (round 1); with the non-temporal loads 2 is (whole step -0.9 ... -1.2 % on two boxes, profiles/r4a_*)
 #endif
 static __global__ void __launch_bounds__(64)
 sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,

@@ -1,5 +1,8 @@
 """Same-box A/B of the WHOLE benchmark step (bench.one_step captured into a hipGraph, replayed) for several builds of the library
-(scripts/build_variants.py):  python scripts/ab_step.py libA.so libB.so ...   -> ms per step per library, interleaved repetitions"""
+(scripts/build_variants.py):  python scripts/ab_step.py libA.so libB.so ...   -> ms per step per library, interleaved repetitions.
+Every graph uses the SAME input tensors and is captured into the SAME memory pool, so corresponding buffers of all variants sit
+at the same addresses: the same library captured twice with buffers of its own differs by up to 2.6 % (placement of the volumes in
+the memory channels, profiles/r3z_*), which would drown a 1 % effect."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +12,11 @@ from ganet_amd import _native
 
 dev = torch.device("cuda:0")
 graphs = {}
-for name in sys.argv[1:]:
+inp = bench.make_inputs(dev)
+pool = torch.cuda.graph_pool_handle()
+for idx, name in enumerate(sys.argv[1:]):
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
-    inp = bench.make_inputs(dev)
+    name = f"{idx}:{name}"
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -20,9 +25,10 @@ for name in sys.argv[1:]:
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, pool=pool):
         keep = bench.one_step(inp)
-    graphs[name] = (g, inp, keep)
+    del keep                      # the next capture reuses the same blocks of the shared pool
+    graphs[name] = (g, inp, None)
 res = {n: [] for n in graphs}
 for rep in range(5):
     for name, (g, _, _) in graphs.items():
