@@ -81,23 +81,25 @@ GA_DEV f2 lds_read_b64(lds_cptr p)
 }
 #endif
 
-// Result stores of the streaming kernels -- directional / adjoint volumes, merged output and mask, the final outputs of an
-// LGA2 chain: written once, read much later or not at all -- are NON-TEMPORAL (`global_store ... nt`), and so are the loads of
-// volumes nothing reads again soon (the directional volumes in the merge; they and the adjoint volumes in the per-pixel
-// gradient kernel): they stream past the L2 / Infinity Cache instead of displacing what the kernels around them re-read (x,
-// gradOut and the mask are read by four scans each, the filter taps by every LGA pass, an interleaved intermediate by the very
-// next kernel).  Measured on seven boxes, whole step, same-box A/B (profiles/r3l_*, r3m_*): -4.1 % on the last two (1.797 ->
-// 1.719 ms; the scans' and the merge's stores -1.4 ... -3.0 %, the per-pixel kernel's loads up to -2.5 %, the LGA2 outputs -2.0 %,
-// the merge's loads -0.4 %).  NOT for the per-pixel kernel's own gradX store (+1 %), every LGA output (an intermediate is
-// re-read at once: ambiguous), the scans' loads (neutral), the LGA tap gather (+3 %: the taps are re-read by the next pass).  Bit masks for A/B builds (scripts/build_variants.py, -DGA_NT_STORES=n -DGA_NT_LOADS=n):
-//   stores: 1 column scans, 2 row scans, 4 merge (output volume), 128 merge (direction mask), 8 per-pixel gradients, 16 LGA apply, 32 LGA filter gradient, 64 LGA apply from an
-//           interleaved input only (the final outputs of an LGA2 chain, not its intermediates)
+// Cache policy.  Result stores of the streaming kernels -- directional / adjoint volumes, merged output and mask, the input
+// gradient, the final outputs of an LGA2 chain: written once, read much later or not at all -- are NON-TEMPORAL
+// (`global_store ... nt`), and so are the loads of the scans' inputs and of the directional volumes in the merge: the data
+// streams through the L2 instead of displacing what the kernels around it re-read (the filter taps are read by every LGA pass,
+// an interleaved intermediate by the very next kernel, a tile's halo by the neighbouring tiles).
+// Measured with the whole step captured into a hipGraph, all variants on the same buffers (scripts/ab_step.py: +-0.2 %;
+// profiles/r3l_*, r3m_*, r4a_* ... r4f_*): stores -3.0 % (nt0 -> 199 on that box; -4.1 ... -4.9 % on earlier ones), loads 5
+// instead of none -2.2 %, the input gradient's store a further -0.3 %.  NOT: the per-pixel gradient kernel's loads (+0.7 %:
+// its forward volumes are read at two pixel offsets), every LGA output (+0.8 ... +1.4 %: the interleaved intermediate is
+// re-read at once), the LGA tap gather (+3 %), the LGA kernels' LDS-DMA copies (+6 ... +10 %).
+// Bit masks for A/B builds (scripts/build_variants.py, -DGA_NT_STORES=n -DGA_NT_LOADS=n):
+//   stores: 1 column scans, 2 row scans, 4 merge (output volume), 128 merge (direction mask), 8 per-pixel gradients (gradX),
+//           16 LGA apply, 32 LGA filter gradient, 64 LGA apply from an interleaved input only (the final outputs of an LGA2 chain)
 //   loads:  1 merge, 2 per-pixel gradients' G / A, 4 scan inputs, 8 per-pixel gradients' x, 16 LGA filter taps
 #ifndef GA_NT_STORES
-#define GA_NT_STORES 199
+#define GA_NT_STORES 207
 #endif
 #ifndef GA_NT_LOADS
-#define GA_NT_LOADS 3
+#define GA_NT_LOADS 5
 #endif
 typedef float ga_f4v __attribute__((ext_vector_type(4)));
 template <bool ON, typename T> GA_DEV void stream_store(T *p, const T &v)

@@ -506,7 +506,11 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
   // "has previous position", two planes in flight per step, capped at 5 waves per SIMD.
   const i64 HW = (i64)H * W;
   const i64 stride = (i64)gridDim.x * blockDim.x;
-  for (i64 pidx = (i64)blockIdx.x * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
+#ifndef GA_POINT_XCD
+#define GA_POINT_XCD 0      // 1: XCD-aware block order (neighbouring blocks share the lines of the one-pixel-shifted reads); A/B builds
+#endif
+  const int bid = GA_POINT_XCD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  for (i64 pidx = (i64)bid * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
     const i64 s = pidx / HW, pix = pidx - s * HW;
     const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
     const i64 vb = s * D * HW + pix;
