@@ -15,7 +15,11 @@ graphs = {}
 inp = bench.make_inputs(dev)
 pool = torch.cuda.graph_pool_handle()
 for idx, name in enumerate(sys.argv[1:]):
-    _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
+    libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value: ganet_set_option before the capture
+    _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname))
+    for kv in filter(None, optstr.split(",")):
+        k, v = kv.split("=")
+        _native._LIB.set_option(k, int(v))
     name = f"{idx}:{name}"
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
