@@ -19,7 +19,10 @@ for idx, name in enumerate(sys.argv[1:]):
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname))
     for kv in filter(None, optstr.split(",")):
         k, v = kv.split("=")
-        _native._LIB.set_option(k, int(v))
+        if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE"):      # read by the Python layer from the environment at every call
+            os.environ[k] = v
+        else:
+            _native._LIB.set_option(k, int(v))
     name = f"{idx}:{name}"
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
