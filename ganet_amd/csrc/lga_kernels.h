@@ -370,9 +370,9 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 
 
 // ---- wave-autonomous forward / data-backward, PLANE-PAIR packing ----------------------------------------
-// lga_apply_dma packs its FMAs along the window's COLUMNS: a 5-wide window needs three aligned register pairs, one slot of
-// which carries a zero weight -- 45 v_pk_fma_f32 for 75 FMAs per plane (83 %), plus 15 further VALU per plane for the parity
-// bookkeeping and the slab reductions.  Here the two halves of a packed FMA are two consecutive PLANES at the same window
+// Packing the FMAs along the window's COLUMNS (round 1's kernels, removed) costs a 5-wide window three aligned register pairs,
+// one slot of which carries a zero weight -- 45 v_pk_fma_f32 for 75 FMAs per plane (83 %), plus 15 further VALU per plane for
+// the parity bookkeeping and the slab reductions.  Here the two halves of a packed FMA are two consecutive PLANES at the same window
 // position.  The ring holds plane PAIRS, interleaved [row][col][2] in LDS, so ONE ds_read_b64 at any (8-byte aligned by
 // construction) window position returns X = (x[2m], x[2m+1]) and with E = (y[2m], y[2m+1]), O = (y[2m+1], y[2m+2]):
 //     E_m     += w( 0)[a,b] * X       (x[2m]   -> y[2m],   x[2m+1] -> y[2m+1])

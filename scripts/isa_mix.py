@@ -6,8 +6,9 @@ sys.path.insert(0, ROOT)
 from ganet_amd import build
 
 HOT = ["sga_col_fwdILi5ELb1ELb1", "sga_col_bwdgILi5ELb0ELb1", "sga_row_fwdILi5ELi32ELi4ELi1ELb0ELb1",
-       "sga_row_bwdgILi5ELi32ELi4ELi1ELb0", "sga_bwd_pointILi4ELb0", "sga_merge_px4", "lga_apply_dmaILi2ELb0",
-       "lga_apply_dmaILi2ELb1", "lga_filter_grad_dmaILi2", "lga_filter_gradILi2", "lga_applyILi2ELb0"]
+       "sga_row_bwdgILi5ELi32ELi4ELi1ELb0", "sga_bwd_pointILi4ELb0", "sga_merge_px4", "lga_apply_ppILi2", "lga_apply_pp_piILi2",
+       "lga_apply_pp_poILi2", "lga_filter_grad_ppILi2", "lga_filter_grad_pp_xpILi2", "lga_filter_grad_pp_gypILi2",
+       "lga_filter_gradILi2", "lga_applyILi2ELb0"]
 print("static instruction counts per kernel (whole kernel body, all paths; gfx950, hipcc -O3; the row-forward kernels are\n"
       "compiled with -fno-slp-vectorize, see ganet_amd/build.py)\n")
 print(f"{'kernel':58s} {'VALU':>6s} {'pk_fma':>6s} {'dpp':>5s} {'SALU':>6s} {'LDS':>5s} {'VMEM':>5s} {'waits':>5s} {'vmcnt0':>6s} {'branch':>6s} {'scratch':>7s} {'VGPR':>5s}")

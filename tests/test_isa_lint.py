@@ -1,7 +1,7 @@
 """Static check on the gfx950 assembly of the LDS-DMA kernels (no GPU needed, hipcc cross-compiles): their marches wait for
 staged planes with hand-counted `s_waitcnt vmcnt(n)`, which is only valid while the compiler adds no vector-memory operation
 of its own to those loops -- a register spill (scratch_load / scratch_store) is one.  scripts/isa_loop_check.py exits 1 if any
-loop with packed FMAs in lga_apply_dma / lga_filter_grad_dma / lga_apply_pp / lga_filter_grad_pp contains scratch traffic."""
+loop with packed FMAs in the lga_apply_pp* / lga_filter_grad_pp* kernels contains scratch traffic."""
 import os
 import shutil
 import subprocess
