@@ -8,10 +8,10 @@ CSRC = os.path.join(_HERE, "csrc")
 # translation units and the extra flags each is compiled with
 SOURCES = {
     "ganet_capi.hip": [],
-    # hipcc's SLP vectoriser packs the scalar FMAs of the horizontal forward recurrence into v_pk_fma_f32
-    # and pays for it in v_mov shuffles (0.098 -> 0.082 ms per scan without it); everything else is a
-    # few per cent faster with it
-    "sga_row_fwd_tu.hip": ["-fno-slp-vectorize"],
+    # hipcc's SLP vectoriser packs the scalar FMAs of the horizontal recurrences into v_pk_fma_f32 and pays
+    # for it in v_mov shuffles (forward scan 0.098 -> 0.082 ms without it, the adjoint spills with it);
+    # everything else is a few per cent faster with it
+    "sga_row_tu.hip": ["-fno-slp-vectorize"],
 }
 HEADERS = ["ga_common.h", "ga_launch.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "sga_col_kernels.inc", "lga_kernels.h", "lga_apply_pp.inc", "lga_filter_grad_pp.inc",
            "misc_kernels.h"]

@@ -219,8 +219,18 @@ template <int CTRL> GA_DEV int dpp_i(int old, int src)
 {
   return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
 }
+GA_DEV int f2i_(float f) { return __builtin_bit_cast(int, f); }
+GA_DEV float i2f_(int i) { return __builtin_bit_cast(float, i); }
 #else
 template <int CTRL> GA_DEV int dpp_i(int old, int src) { return hipsim::update_dpp(old, src, CTRL); }
+#endif
+
+// shift patterns whose source-less lanes read ZERO (bound_ctrl): with no `old` operand the compiler folds the move into the
+// consumer (v_fmac_f32_dpp) instead of emitting v_mov_b32 0 + v_mov_b32_dpp + op
+#if !defined(GA_HIPSIM) && !defined(GA_NO_DPP)
+template <int CTRL> GA_DEV float dpp_zero_f(float src) { return i2f_(__builtin_amdgcn_mov_dpp(f2i_(src), CTRL, 0xF, 0xF, true)); }
+#else
+template <int CTRL> GA_DEV float dpp_zero_f(float src) { union { float f; int i; } a, b; a.f = src; b.i = dpp_i<CTRL>(0, a.i); return b.f; }
 #endif
 
 // full-permutation patterns (xor / mirror): every lane has an in-row source, so `old` is
@@ -265,6 +275,19 @@ template <int GD> GA_DEV float seg_from_next(float old, float src, int lg)
   const float r = dpp_f<DPP_ROW_SHL1>(old, src);
   if (GD == 16) return r;
   return lg == GD - 1 ? old : r;
+}
+// the same with 0 for the segment's first / last lane (the adjoint scans)
+template <int GD> GA_DEV float seg_from_prev0(float src, int lg)
+{
+  if (GD == 64) return dpp_zero_f<DPP_WAVE_SHR1>(src);
+  if (GD == 16) return dpp_zero_f<DPP_ROW_SHR1>(src);
+  return seg_from_prev<GD>(0.f, src, lg);
+}
+template <int GD> GA_DEV float seg_from_next0(float src, int lg)
+{
+  if (GD == 64) return dpp_zero_f<DPP_WAVE_SHL1>(src);
+  if (GD == 16) return dpp_zero_f<DPP_ROW_SHL1>(src);
+  return seg_from_next<GD>(0.f, src, lg);
 }
 // max of two values that are known not to be signalling NaNs (results of arithmetic): fmaxf()
 // makes hipcc canonicalise each operand first (an extra v_max_f32 x, x per element)

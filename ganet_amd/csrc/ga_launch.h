@@ -69,7 +69,19 @@ inline int row_dpl(int D)
   return best;
 }
 
-// sga_row_fwd_tu.hip: horizontal forward scans (direction 2 = right, 3 = left); the caller checks the launch
+// adjoint scan: 1 tile + mask per row
+#ifndef GA_ROW_LN_B
+#define GA_ROW_LN_B 1
+#endif
+constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = GA_ROW_LN_B;
+inline size_t row_smem_bwdg(int D)
+{
+  return sizeof(float) * ROW_LN_B * ((size_t)(D + 1) * RowCfg<ROW_SBH_B, ROW_PAD_B>::RS + 5 * ROW_SBH_B + ROW_SBH_B / 2);
+}
+
+// sga_row_tu.hip: horizontal scans (direction 2 = right, 3 = left), forward and adjoint; the caller checks the launch
+void launch_row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
+                     int S, int D, int H, int W, int dir, hipStream_t st);
 void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
                     int out_mode = 0, int C = 1, const float *scale = nullptr, const float *shift = nullptr);
 

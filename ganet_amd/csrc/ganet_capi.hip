@@ -203,16 +203,6 @@ int check_dims5(const char *who, int N, int C, int D, int H, int W)
 }
 
 // ---- horizontal scans, one wavefront per row (sga_row_kernels.h) --------------------------
-#ifndef GA_ROW_LN_B
-#define GA_ROW_LN_B 1
-#endif
-constexpr int ROW_SBH_B = 32, ROW_PAD_B = 4, ROW_LN_B = GA_ROW_LN_B;   // adjoint scan: 1 tile + mask per row
-size_t row_smem_bwdg(int D)
-{
-  const size_t mask_words = ((size_t)D * (RowCfg<ROW_SBH_B, ROW_PAD_B>::PP + 1) + 3) & ~(size_t)3;
-  return sizeof(float) * ROW_LN_B * ((size_t)D * RowCfg<ROW_SBH_B, ROW_PAD_B>::RS + mask_words + 5 * ROW_SBH_B +
-                                     ROW_SBH_B / 2);
-}
 
 bool rowwave_ok(int D, int W, int dir, size_t smem)
 {
@@ -222,7 +212,7 @@ bool rowwave_ok(int D, int W, int dir, size_t smem)
 int row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
             int out_mode = 0, int C = 1, const float *scale = nullptr, const float *shift = nullptr)
 {
-  launch_row_fwd(x, g, A, S, D, H, W, dir, st, out_mode, C, scale, shift);   // sga_row_fwd_tu.hip (own translation unit, own flags)
+  launch_row_fwd(x, g, A, S, D, H, W, dir, st, out_mode, C, scale, shift);   // sga_row_tu.hip (own translation unit, own flags)
   return check_launch("sga row forward");
 }
 
@@ -309,10 +299,10 @@ int col_bwdg_wide(const float *g, const uint8_t *mask, const uint16_t *kp, const
   const bool m16 = W % 16 == 0 && aligned16(mask);
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
-    if (dir == 1 && m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
-    else if (dir == 1) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);   \
-    else if (m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);        \
-    else GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);                \
+    if (dir == 1 && m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
+    else if (dir == 1) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, true, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);   \
+    else if (m16) GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);        \
+    else GA_LAUNCH_SMEM_BIG((sga_col_bwdg_wide<P, false, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);                \
   }
   X(3)
 #undef X
@@ -331,35 +321,31 @@ int col_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const floa
   const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
   // the adjoint of `down` (0) walks rows upwards (H-1..0), of `up` (1) downwards
   const bool m16 = W % 16 == 0 && aligned16(mask);
+  // (lanes wholly inside / outside [0, D): the leaner recurrence of bwdg_step<FULL>, instantiated for the depths the models use
+  //  -- 33 and 48 at three, 65 at five disparities per lane)
+  const bool full = D % dpl == 0;
+#define L(P, ASC, M, F) GA_LAUNCH_SMEM((sga_col_bwdg<P, ASC, M, F>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir)
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
-    if (dir == 1 && m16) GA_LAUNCH_SMEM((sga_col_bwdg<P, true, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
-    else if (dir == 1) GA_LAUNCH_SMEM((sga_col_bwdg<P, true, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);   \
-    else if (m16) GA_LAUNCH_SMEM((sga_col_bwdg<P, false, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);        \
-    else GA_LAUNCH_SMEM((sga_col_bwdg<P, false, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);                \
+    constexpr bool FL = (P) == 3 || (P) == 5;                                                       \
+    if (full && FL) {                                                                               \
+      if (dir == 1 && m16) L(P, true, true, FL); else if (dir == 1) L(P, true, false, FL);          \
+      else if (m16) L(P, false, true, FL); else L(P, false, false, FL);                             \
+    } else {                                                                                        \
+      if (dir == 1 && m16) L(P, true, true, false); else if (dir == 1) L(P, true, false, false);    \
+      else if (m16) L(P, false, true, false); else L(P, false, false, false);                       \
+    }                                                                                               \
   }
   GA_ROW_DPLS(X)
 #undef X
+#undef L
   return check_launch("sga column-block adjoint scan");
 }
 
 int row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
              int S, int D, int H, int W, int dir, hipStream_t st)
 {
-  RowGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.total_rows = S * H;
-  geo.out_mode = 0; geo.C = 1; geo.scale = nullptr; geo.shift = nullptr;
-  const int dpl = row_dpl(D);
-  const size_t smem = row_smem_bwdg(D);
-  const dim3 grid((S * H + ROW_LN_B - 1) / ROW_LN_B), block(64);
-  // the adjoint of `right` (2) walks w downwards, of `left` (3) upwards
-#define X(P)                                                                                        \
-  if (dpl == (P)) {                                                                                 \
-    if (dir == 2) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, true>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);  \
-    else GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, false>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir);          \
-  }
-  GA_ROW_DPLS(X)
-#undef X
+  launch_row_bwdg(g, mask, kp, gout, G, S, D, H, W, dir, st);       // sga_row_tu.hip
   return check_launch("sga row adjoint scan");
 }
 

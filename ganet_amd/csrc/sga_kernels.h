@@ -287,33 +287,73 @@ sga_fwd_rowvec(const float *__restrict__ x, const float *__restrict__ g, float *
 
 // ---- reverse-scan adjoint, one visited position -------------------------------------
 // Gn: G at the previously visited position (forward p+1); wn its guidance; sgn = sum_d Gn.
-template <int GD, int DPL, typename MaskT>
+// FULL (the caller guarantees D % DPL == 0, so a lane lies wholly inside or wholly outside [0, D)): the range test of every
+// element collapses to two per-lane values -- `dl`, the direction an inside lane compares its mask bytes with (-1 outside: no
+// byte matches), and a zero for the one term an outside lane could receive from an inside one (lo of the first outside lane);
+// outside lanes then stay exactly 0 by themselves.
+// PRE: `go` is the MASKED gradient already -- [mask == dir] * gradOut for elements inside [0, D), 0 outside (the row kernel
+// applies the mask when it stages a tile, where all 64 lanes hold different elements, instead of here, where a 16-lane
+// recurrence is mirrored four times: 2 instead of 10-15 instructions per position for it); mk is not read.
+template <int GD, int DPL, typename MaskT, bool FULL = false, bool PRE = false>
 GA_DEV void bwdg_step(const float (&go)[DPL], const MaskT (&mk)[DPL], float (&Gn)[DPL],
                       float (&wn)[5], float &sgn, const float (&w)[5], int kp, bool has_nx,
                       const LaneCtx &c, int D, int dir)
 {
   float G[DPL];
+  if (FULL) {
+    const bool in = c.cap > 0.f;                       // (lane_cap: +inf inside)
+    if (PRE) {
 #pragma unroll
-  for (int i = 0; i < DPL; i++) G[i] = (c.d0 + i < D && (int)mk[i] == dir) ? go[i] : 0.f;
-  if (has_nx) {
-    const float lo = seg_from_prev<GD>(0.f, Gn[DPL - 1], c.lg);
-    const float hi = seg_from_next<GD>(0.f, Gn[0], c.lg);
-    const float t4 = wn[4] * sgn;
+      for (int i = 0; i < DPL; i++) G[i] = go[i];
+    } else {
+      int dl = in ? dir : -1;
+#if !defined(GA_HIPSIM)
+      asm volatile("" : "+v"(dl));                     // (left visible, hipcc turns it back into `in && mask == dir`: the s_and again)
+#endif
 #pragma unroll
-    for (int i = 0; i < DPL; i++) {
-      const float up = i < DPL - 1 ? Gn[i + 1] : hi;
-      const float dn = i > 0 ? Gn[i - 1] : lo;
-      float t = G[i];
-      t = fmaf(Gn[i], wn[1], t);
-      t = fmaf(up, wn[2], t);
-      t = fmaf(dn, wn[3], t);
-      if (c.d0 + i == kp) t += t4;
-      G[i] = (c.d0 + i < D) ? t : 0.f;
+      for (int i = 0; i < DPL; i++) G[i] = (int)mk[i] == dl ? go[i] : 0.f;
+    }
+    if (has_nx) {
+      const float lo = seg_from_prev0<GD>(Gn[DPL - 1], c.lg);
+      const float hi = seg_from_next0<GD>(Gn[0], c.lg);
+      const float w3 = in ? wn[3] : 0.f;               // the first outside lane receives nothing from the last inside one
+      const float t4 = wn[4] * sgn;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        const float up = i < DPL - 1 ? Gn[i + 1] : hi;
+        const float dn = i > 0 ? Gn[i - 1] : lo;
+        float t = G[i];
+        t = fmaf(Gn[i], wn[1], t);
+        t = fmaf(up, wn[2], t);
+        t = fmaf(dn, w3, t);
+        if (c.d0 + i == kp) t += t4;
+        G[i] = t;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DPL; i++) G[i] = PRE ? go[i] : ((c.d0 + i < D && (int)mk[i] == dir) ? go[i] : 0.f);
+    if (has_nx) {
+      const float lo = seg_from_prev0<GD>(Gn[DPL - 1], c.lg);
+      const float hi = seg_from_next0<GD>(Gn[0], c.lg);
+      const float t4 = wn[4] * sgn;
+#pragma unroll
+      for (int i = 0; i < DPL; i++) {
+        const float up = i < DPL - 1 ? Gn[i + 1] : hi;
+        const float dn = i > 0 ? Gn[i - 1] : lo;
+        float t = G[i];
+        t = fmaf(Gn[i], wn[1], t);
+        t = fmaf(up, wn[2], t);
+        t = fmaf(dn, wn[3], t);
+        if (c.d0 + i == kp) t += t4;
+        G[i] = (c.d0 + i < D) ? t : 0.f;
+      }
     }
   }
-  float sg = 0.f;
+  float sg = G[0];
+  Gn[0] = G[0];
 #pragma unroll
-  for (int i = 0; i < DPL; i++) { Gn[i] = G[i]; sg += G[i]; }
+  for (int i = 1; i < DPL; i++) { Gn[i] = G[i]; sg += G[i]; }
 #pragma unroll
   for (int t = 0; t < 5; t++) wn[t] = w[t];
   sgn = seg_allsum<GD>(sg);

@@ -224,9 +224,10 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 // ---- adjoint scan (backward step 1, see sga_kernels.h) with the same row staging --------------
 // grid.x = ceil(S*H / LN), block = 64.  desc: VISIT order w = W-1..0 (adjoint of `right`).
 // The G tile overwrites the gradOut tile in place (a lane rewrites exactly the cells it read).
-// dynamic LDS per image row: D*RS (gradOut -> G) + roundup4(D*(PP+1)) mask words + 5*SBH (w)
-// + SBH/2 words (kp as uint16).
-template <int DPL, int SBH, int PAD, int LN, bool desc>
+// dynamic LDS per image row: (D+1)*RS ([mask == dir] * gradOut -> G; one row of zeros) + 5*SBH (w) + SBH/2 words (kp as uint16).
+// The direction mask is applied when a tile is committed to LDS -- 64 lanes, 64 different pieces -- not in the recurrence,
+// whose 16 lanes are mirrored four times: 2 instead of 15 instructions per position, and no mask tile.
+template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL>     // FULL: D % DPL == 0 (bwdg_step)
 __global__ void __launch_bounds__(64, (DPL <= 5 ? 3 : 1))
 sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
              const uint16_t *__restrict__ kp, const float *__restrict__ gout,
@@ -236,12 +237,11 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
   GA_DYN_SMEM(smem);
   const int D = geo.D, W = geo.W;
   const int total_rows = geo.total_rows;
-  constexpr int MS = C::PP + 1;
-  const int TS = D * C::RS;
-  const int MW = (D * MS + 3) & ~3;
-  float *gt = smem;                                            // [LN][D][RS]
-  uint32_t *mt = reinterpret_cast<uint32_t *>(gt + LN * TS);   // [LN][MW]
-  float *wt = reinterpret_cast<float *>(mt + LN * MW);         // [LN][5][SBH]
+  const int TS = (D + 1) * C::RS;
+  float *gt = smem;                                            // [LN][D + 1][RS]: the MASKED gradient ([mask == dir] * gradOut,
+                                                               // applied by commit()), G in place; row D stays zero: what the
+                                                               // elements outside [0, D) of the last lanes read
+  float *wt = gt + LN * TS;                                    // [LN][5][SBH]
   uint32_t *kt = reinterpret_cast<uint32_t *>(wt + LN * 5 * SBH);   // [LN][SBH/2]
   const int lane = threadIdx.x;
   const int rl = lane & 15;
@@ -272,8 +272,12 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
 #pragma unroll
   for (int t = 0; t < 5; t++) wn[t] = 0.f;
   float *gr = gt + r * TS;
-  const uint32_t *mr = mt + r * MW, *kr = kt + r * (SBH / 2);
+  const uint32_t *kr = kt + r * (SBH / 2);
   const float *wr = wt + r * 5 * SBH;
+  if (lane < C::RS) {
+#pragma unroll
+    for (int q = 0; q < LN; q++) gt[q * TS + D * C::RS + lane] = 0.f;
+  }
 
   // software pipeline as in sga_row_fwd: the next batch's gradOut / mask / guidance / arg-max pieces
   // are requested before the current batch is computed and committed to LDS after it
@@ -311,9 +315,10 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
       for (int n = 0; n < NPC; n++) {
         const int pl = n * C::PPI + psub;
         if (pl < D && col_ok) {
+          const uint32_t m = mpre[q][n];       // the winning direction of the piece's four elements, one byte each
           *reinterpret_cast<f4 *>(gt + q * TS + pl * C::RS + 4 * piece) =
-              f4{gpre[q][n][0], gpre[q][n][1], gpre[q][n][2], gpre[q][n][3]};
-          mt[q * MW + pl * MS + piece] = mpre[q][n];
+              f4{(int)(m & 0xffu) == dir ? gpre[q][n][0] : 0.f, (int)((m >> 8) & 0xffu) == dir ? gpre[q][n][1] : 0.f,
+                 (int)((m >> 16) & 0xffu) == dir ? gpre[q][n][2] : 0.f, (int)(m >> 24) == dir ? gpre[q][n][3] : 0.f};
         }
       }
       if (psub < 5 && col_ok)
@@ -342,12 +347,10 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
         const bool first_group = !started;
         started = true;
         f4 gov[DPL], wv[5], ov[DPL];
-        uint32_t mw[DPL];
 #pragma unroll
         for (int i = 0; i < DPL; i++) {
-          const int d = c.d0 + i < D ? c.d0 + i : D - 1;
+          const int d = c.d0 + i < D ? c.d0 + i : D;         // (row D: zeros)
           gov[i] = *reinterpret_cast<const f4 *>(gr + d * C::RS + 4 * cq);
-          mw[i] = mr[d * MS + cq];
         }
 #pragma unroll
         for (int t = 0; t < 5; t++) wv[t] = *reinterpret_cast<const f4 *>(wr + t * SBH + 4 * cq);
@@ -356,19 +359,16 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
         for (int k = 0; k < 4; k++) {
           const int kk = desc ? 3 - k : k;
           float go[DPL], w[5];
-          uint8_t mk[DPL];
+          const uint8_t mk[DPL] = {};          // (not read: the tile holds the masked gradient)
 #pragma unroll
-          for (int i = 0; i < DPL; i++) {
-            go[i] = f4_get(gov[i], kk);
-            mk[i] = (uint8_t)(mw[i] >> (8 * kk));
-          }
+          for (int i = 0; i < DPL; i++) go[i] = f4_get(gov[i], kk);
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
           const int kpv = (int)(((kk < 2 ? k01 : k23) >> (16 * (kk & 1))) & 0xffffu);
 #if GA_SCAN_ABLATE & 1
-          for (int i = 0; i < DPL; i++) Gn[i] = (int)mk[i] == dir ? go[i] + w[0] : (float)kpv;
+          for (int i = 0; i < DPL; i++) Gn[i] = go[i] + w[0] + (float)kpv;
 #else
-          bwdg_step<16, DPL, uint8_t>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
+          bwdg_step<16, DPL, uint8_t, FULL, true>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
 #endif
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]);

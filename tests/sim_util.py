@@ -19,7 +19,7 @@ def build_sim():
     if os.path.exists(SIM_SO) and all(os.path.getmtime(d) <= os.path.getmtime(SIM_SO) for d in deps):
         return SIM_SO
     cmd = ["g++", "-std=c++17", "-O1", "-DGA_HIPSIM", "-I", os.path.join(HERE, "hipsim"), "-I", CSRC,
-           "-x", "c++", os.path.join(CSRC, "ganet_capi.hip"), os.path.join(CSRC, "sga_row_fwd_tu.hip"),
+           "-x", "c++", os.path.join(CSRC, "ganet_capi.hip"), os.path.join(CSRC, "sga_row_tu.hip"),
            "-shared", "-fPIC", "-o", SIM_SO]
     subprocess.run(cmd, check=True)
     return SIM_SO
