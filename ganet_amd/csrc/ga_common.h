@@ -318,9 +318,16 @@ template <int GD> GA_DEV float seg_allmax(float v)
   if (GD >= 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
   if (GD >= 16) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
 #endif
-  if (GD == 64) {     // every lane of a row now holds the row's maximum: combine the four rows through scalars
+  if (GD == 64) {     // every lane of a row now holds the row's maximum
+#if defined(GA_HIPSIM) || defined(GA_NO_DPP)
     const float r0 = wave_readlane_f(v, 0), r1 = wave_readlane_f(v, 16), r2 = wave_readlane_f(v, 32), r3 = wave_readlane_f(v, 48);
     v = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+#else
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, one read of lane 63 (see seg_allsum)
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    v = wave_readlane_f(v, 63);
+#endif
   }
   return v;
 }
@@ -330,9 +337,18 @@ template <int GD> GA_DEV float seg_allsum(float v)
   if (GD >= 4) v += dpp_perm_f<DPP_QP_XOR2>(v);
   if (GD >= 8) v += dpp_perm_f<DPP_ROW_HALF_MIRROR>(v);
   if (GD >= 16) v += dpp_perm_f<DPP_ROW_MIRROR>(v);
-  if (GD == 64) {
+  if (GD == 64) {     // every lane of a row holds the row's sum: (r0 + r1) + (r2 + r3)
+#if defined(GA_HIPSIM) || defined(GA_NO_DPP)
     const float r0 = wave_readlane_f(v, 0), r1 = wave_readlane_f(v, 16), r2 = wave_readlane_f(v, 32), r3 = wave_readlane_f(v, 48);
     v = (r0 + r1) + (r2 + r3);
+#else
+    // row_bcast:15 into rows 1 and 3 (r1 + r0, r3 + r2), row_bcast:31 into rows 2 and 3 (row 3: (r3 + r2) + (r0 + r1)), one read
+    // of lane 63: two DPP adds and one v_readlane instead of four v_readlane and three adds
+    // (written out: from the builtin hipcc makes v_mov_b32 0 + v_mov_b32_dpp + v_add_f32 per step)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    v = wave_readlane_f(v, 63);
+#endif
   }
   return v;
 }

@@ -54,8 +54,9 @@ template <int SBH, int PAD> struct RowCfg {
 // grid.x = ceil(S*H / LN), block = 64: DPP row r of the wave owns image row blockIdx.x*LN + r
 // (rows >= LN mirror row r % LN).  desc: visit w = W-1 .. 0 (direction `left`).
 // dynamic LDS: LN * (D*RS + 5*SBH) floats (the A tile aliases the x tile).
-template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL>
-__global__ void __launch_bounds__(64, (DPL <= 5 ? 3 : 1))   // (<= 168 VGPRs incl. the prefetched tile where that fits)
+// GD = 64, NPCT: see sga_row_bwdg.
+template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL, int GD = 16, int NPCT = 0>
+__global__ void __launch_bounds__(64, (GD == 64 && DPL == 1 ? 4 : DPL <= 5 ? 3 : 1))   // (<= 168 VGPRs incl. the prefetched tile where that fits)
 sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ A,
             RowGeom geo)
 {
@@ -67,10 +68,11 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   float *at = xt;                         // A overwrites the x tile in place (a lane rewrites
                                           // exactly the cells it read; mirror rows do not write)
   float *wt = xt + LN * D * C::RS;        // [LN][5][SBH]
+  static_assert(GD == 16 || (GD == 64 && LN == 1), "the depth axis lies in one DPP row (mirrored) or over the whole wavefront");
   const int lane = threadIdx.x;
-  const int rl = lane & 15;
-  const int r = (lane >> 4) % LN;
-  const bool owner = (lane >> 4) < LN;    // this lane's DPP row carries row r (not a mirror)
+  const int rl = GD == 64 ? lane : lane & 15;
+  const int r = GD == 64 ? 0 : (lane >> 4) % LN;
+  const bool owner = GD == 64 || (lane >> 4) < LN;    // this lane's DPP row carries row r (not a mirror)
   const int d0 = rl * DPL;
   LaneCtx c;
   c.lg = rl; c.d0 = d0; c.line_ok = true; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
@@ -110,7 +112,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
   // batch; scripts/isa_lint.py counts such patterns).  Loads are unconditional (addresses clamped
   // into the row, the clamped copies are never committed): a conditional load makes the compiler
   // guard every later use of its registers with vmcnt(0).
-  constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;      // pieces per lane and image row
+  constexpr int NPC = NPCT ? NPCT : (GD * DPL + C::PPI - 1) / C::PPI;      // pieces per lane and image row
   float xpre[LN][NPC][4], wpre[LN][4];       // (plain floats: an f4 array carried around the loop stays in scratch)
   auto batch_col0 = [&](int b) { return (desc ? nb - 1 - b : b) * SBH - a0; };     // column of the batch's first element (may be < 0)
   auto batch_col = [&](int b) { return batch_col0(b) + 4 * piece; };
@@ -183,7 +185,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 #if GA_SCAN_ABLATE & 1
           for (int i = 0; i < DPL; i++) Ap[i] = xs[i] + w[0];     // (A/B only: the tile path without the recurrence)
 #else
-          fwd_step<16, DPL, FULL>(xs, w, Ap, m, k == 0 && first_group, c, D);
+          fwd_step<GD, DPL, FULL>(xs, w, Ap, m, k == 0 && first_group, c, D);
 #endif
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Ap[i]);
@@ -227,8 +229,11 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
 // dynamic LDS per image row: (D+1)*RS ([mask == dir] * gradOut -> G; one row of zeros) + 5*SBH (w) + SBH/2 words (kp as uint16).
 // The direction mask is applied when a tile is committed to LDS -- 64 lanes, 64 different pieces -- not in the recurrence,
 // whose 16 lanes are mirrored four times: 2 instead of 15 instructions per position, and no mask tile.
-template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL>     // FULL: D % DPL == 0 (bwdg_step)
-__global__ void __launch_bounds__(64, (DPL <= 5 ? 3 : 1))
+// GD = 64: the depth axis over all 64 lanes (DPL disparities each, D <= 64 * DPL) instead of over one 16-lane DPP row that is
+// mirrored in the other three -- 2.5x fewer elements per lane at D = 65 for three more cross-lane steps per position; NPCT: the
+// planes a lane stages per batch, ceil(D_max / PPI), when that is less than GD * DPL / PPI.
+template <int DPL, int SBH, int PAD, int LN, bool desc, bool FULL, int GD = 16, int NPCT = 0>     // FULL: D % DPL == 0 (bwdg_step)
+__global__ void __launch_bounds__(64, (GD == 64 ? 4 : DPL <= 5 ? 3 : 1))
 sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
              const uint16_t *__restrict__ kp, const float *__restrict__ gout,
              float *__restrict__ G, RowGeom geo, int dir)
@@ -243,10 +248,11 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
                                                                // elements outside [0, D) of the last lanes read
   float *wt = gt + LN * TS;                                    // [LN][5][SBH]
   uint32_t *kt = reinterpret_cast<uint32_t *>(wt + LN * 5 * SBH);   // [LN][SBH/2]
+  static_assert(GD == 16 || (GD == 64 && LN == 1), "the depth axis lies in one DPP row (mirrored) or over the whole wavefront");
   const int lane = threadIdx.x;
-  const int rl = lane & 15;
-  const int r = (lane >> 4) % LN;
-  const bool owner = (lane >> 4) < LN;
+  const int rl = GD == 64 ? lane : lane & 15;
+  const int r = GD == 64 ? 0 : (lane >> 4) % LN;
+  const bool owner = GD == 64 || (lane >> 4) < LN;
   LaneCtx c;
   c.lg = rl; c.d0 = rl * DPL; c.line_ok = true; c.s = 0; c.q = 0; c.cap = lane_cap(c.d0, D);
   const int piece = lane % C::PP, psub = lane / C::PP;
@@ -281,7 +287,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
 
   // software pipeline as in sga_row_fwd: the next batch's gradOut / mask / guidance / arg-max pieces
   // are requested before the current batch is computed and committed to LDS after it
-  constexpr int NPC = (16 * DPL + C::PPI - 1) / C::PPI;
+  constexpr int NPC = NPCT ? NPCT : (GD * DPL + C::PPI - 1) / C::PPI;
   float gpre[LN][NPC][4], wpre[LN][4];
   uint32_t mpre[LN][NPC], kpre[LN][2];
   auto batch_col0 = [&](int b) { return (desc ? nb - 1 - b : b) * SBH - a0; };
@@ -368,7 +374,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
 #if GA_SCAN_ABLATE & 1
           for (int i = 0; i < DPL; i++) Gn[i] = go[i] + w[0] + (float)kpv;
 #else
-          bwdg_step<16, DPL, uint8_t, FULL, true>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
+          bwdg_step<GD, DPL, uint8_t, FULL, true>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
 #endif
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]);

@@ -8,6 +8,13 @@
 // libganet_hip.so.
 #include "ga_launch.h"
 
+#ifndef GA_ROW_GD64
+#define GA_ROW_GD64 1        // forward: depth axis over the whole wavefront for the models' depths
+#endif
+#ifndef GA_ROW_BWDG_GD64
+#define GA_ROW_BWDG_GD64 1   // the same for the adjoint
+#endif
+
 namespace ga {
 
 void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
@@ -20,6 +27,18 @@ void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int 
   const bool full = dpl > 0 && D % dpl == 0;     // lanes wholly inside / outside [0, D): leaner recurrence
   const size_t smem = row_smem_fwd(D);
   const dim3 grid((S * H + ROW_LN_F - 1) / ROW_LN_F), block(64);
+#if GA_ROW_GD64
+  // the depths the models use, with the depth axis over the whole wavefront: 33 and 48 at one, 65 at two disparities per lane
+#define L64(P, DESC, F, NP) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, 1, DESC, F, 64, NP>), grid, block, smem, st, x, g, A, geo)
+  if (ROW_LN_F == 1 && D <= 40) { if (dir == 3) L64(1, true, true, 5); else L64(1, false, true, 5); return; }
+  if (ROW_LN_F == 1 && D <= 48) { if (dir == 3) L64(1, true, true, 6); else L64(1, false, true, 6); return; }
+  if (ROW_LN_F == 1 && D > 64 && D <= 72) {
+    if (D % 2 == 0) { if (dir == 3) L64(2, true, true, 9); else L64(2, false, true, 9); }
+    else { if (dir == 3) L64(2, true, false, 9); else L64(2, false, false, 9); }
+    return;
+  }
+#undef L64
+#endif
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
     if (dir == 3 && full) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, ROW_LN_F, true, true>), grid, block, smem, st, x, g, A, geo);  \
@@ -44,6 +63,18 @@ void launch_row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, co
   // recurrence of bwdg_step<FULL>, instantiated for the depths the models use (33 and 48 at three, 65 at five per lane)
   const bool full = dpl > 0 && D % dpl == 0;
 #define L(P, DESC, F) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, DESC, F>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir)
+#if GA_ROW_BWDG_GD64
+  // the depths the models use, with the depth axis over the whole wavefront: 33 and 48 at one, 65 at two disparities per lane
+#define L64(P, DESC, F, NP) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, 1, DESC, F, 64, NP>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir)
+  if (ROW_LN_B == 1 && D <= 40) { if (dir == 2) L64(1, true, true, 5); else L64(1, false, true, 5); return; }
+  if (ROW_LN_B == 1 && D <= 48) { if (dir == 2) L64(1, true, true, 6); else L64(1, false, true, 6); return; }
+  if (ROW_LN_B == 1 && D > 64 && D <= 72) {
+    if (D % 2 == 0) { if (dir == 2) L64(2, true, true, 9); else L64(2, false, true, 9); }
+    else { if (dir == 2) L64(2, true, false, 9); else L64(2, false, false, 9); }
+    return;
+  }
+#undef L64
+#endif
 #define X(P)                                                                                        \
   if (dpl == (P)) {                                                                                 \
     constexpr bool FL = (P) == 3 || (P) == 5;                                                       \
