@@ -195,10 +195,10 @@ def stage_timings(inp, iters=5):
 # which kernels make up one launch of each family (names as in profiles/traffic_pmc.json)
 _FAMILY_KERNELS = {
     "sga_scan_fwd": [["sga_col_fwd<5, true, true>"], ["sga_col_fwd<5, false, true>"],
-                     ["sga_row_fwd<5, 32, 4, 1, false, true>"], ["sga_row_fwd<5, 32, 4, 1, true, true>"]],
+                     ["sga_row_fwd<2, 32, 4, 1, false, false, 64, 9>"], ["sga_row_fwd<2, 32, 4, 1, true, false, 64, 9>"]],
     "sga_merge_argmax": [["sga_merge_px4"]],
-    "sga_bwd_scan": [["sga_col_bwdg<5, false, true>"], ["sga_col_bwdg<5, true, true>"],
-                     ["sga_row_bwdg<5, 32, 4, 1, true>"], ["sga_row_bwdg<5, 32, 4, 1, false>"]],
+    "sga_bwd_scan": [["sga_col_bwdg<5, false, true, true>"], ["sga_col_bwdg<5, true, true, true>"],
+                     ["sga_row_bwdg<2, 32, 4, 1, true, false, 64, 9>"], ["sga_row_bwdg<2, 32, 4, 1, false, false, 64, 9>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false>"]],
     "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_xp<2, 3, 0>", "lga_apply_pp_po<2, true, false>"],
                                          ["lga_filter_grad_pp_gyp<2, 3, 0>", "lga_apply_pp_pi<2, true, false>"]],
