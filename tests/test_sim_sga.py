@@ -72,6 +72,17 @@ def test_horizontal_kernel_families(sim, port_oracle, shape, rowwave):
         sim.set_option("GANET_SGA_ROWWAVE", 1)
 
 
+@pytest.mark.parametrize("D", [1, 2, 39, 40, 41, 47, 49, 64, 66, 71, 72, 73])
+def test_horizontal_depth_over_wavefront_boundaries(sim, port_oracle, D):
+    """The row kernels carry the depth axis over the whole wavefront for D <= 40 (1 disparity per lane, 5 staged pieces),
+    D <= 48 (1, 6) and 64 < D <= 72 (2, 9; even D: lanes wholly inside / outside) and in one mirrored 16-lane DPP row otherwise
+    (sga_row_tu.hip): every boundary of that dispatch, rows of two batches with a partial one, against the oracle."""
+    shape = (1, 2, D, 2, 40)
+    x, gs, go = pc.sga_inputs(shape, seed=100 + D)
+    err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+    assert max(err.values()) < 2e-5, err
+
+
 @pytest.mark.parametrize("mode", ["plain", "guard_start", "late_reversed"])
 @pytest.mark.parametrize("shape", [(1, 1, 192, 5, 16), (1, 2, 65, 7, 20), (2, 1, 7, 9, 8), (1, 1, 100, 6, 36), (1, 1, 150, 3, 12),
                                    (1, 1, 3, 1, 4), (1, 1, 191, 2, 40)])
