@@ -562,7 +562,10 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   return check_launch("lga apply");
 }
 
-// one LGA pass / data-backward with one side in the pair-interleaved layout (lga_apply_pp_pi / lga_apply_pp_po)
+#ifndef GA_LGA_PLANAR
+#define GA_LGA_PLANAR 1
+#endif
+// one LGA pass / data-backward with one side in the pair-interleaved layout (lga_apply_pp_pi / lga_apply_pp_po / lga_apply_pp_xo)
 int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, bool transposed, bool x_paired,
                       hipStream_t st)
 {
@@ -576,6 +579,9 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   if (x_paired) {
     if (transposed) GA_LAUNCH((lga_apply_pp_pi<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
     else GA_LAUNCH((lga_apply_pp_pi<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+  } else if (GA_LGA_PLANAR && W % 4 == 0) {      // API-layout input staged planar, two 16-byte copies per plane pair
+    if (transposed) GA_LAUNCH((lga_apply_pp_xo<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    else GA_LAUNCH((lga_apply_pp_xo<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
   } else {
     if (transposed) GA_LAUNCH((lga_apply_pp_po<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
     else GA_LAUNCH((lga_apply_pp_po<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);

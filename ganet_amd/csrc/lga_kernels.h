@@ -393,6 +393,35 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_ABLATE
 #define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs
 #endif
+// Two dwords of one LDS row pair in ONE instruction, into a register pair: p[O0] and p[O1] (dword offsets, at most 255).  The
+// planar staging of lga_apply_pp.inc (GA_PP_IN = 2) keeps the two planes of a pair LGA_TW + 8 dwords apart; written as two
+// loads hipcc pairs up neighbouring COLUMNS instead and assembles the plane pairs with 32 v_mov per plane pair.  The asm is
+// invisible to the compiler's wait insertion: lds_rows_ready() below is the counted wait that goes with it.
+#if !defined(GA_HIPSIM)
+template <int O0, int O1> GA_DEV f2 lds_read2_b32(lds_cptr p)
+{
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2_b32 offsets are 8 bits");
+  f2 r;
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(p), "n"(O0), "n"(O1));
+  return r;
+}
+// the five cells of window row TROW (0, 1, 2) relative to `p`, planes PLD dwords apart, rows ROWF dwords apart
+template <int TROW, int ROWF, int PLD> GA_DEV void lds_read2_row5(f2 (&row)[5], lds_cptr p)
+{
+  row[0] = lds_read2_b32<TROW * ROWF + 0, TROW * ROWF + 0 + PLD>(p);
+  row[1] = lds_read2_b32<TROW * ROWF + 1, TROW * ROWF + 1 + PLD>(p);
+  row[2] = lds_read2_b32<TROW * ROWF + 2, TROW * ROWF + 2 + PLD>(p);
+  row[3] = lds_read2_b32<TROW * ROWF + 3, TROW * ROWF + 3 + PLD>(p);
+  row[4] = lds_read2_b32<TROW * ROWF + 4, TROW * ROWF + 4 + PLD>(p);
+}
+// wait until at most N LDS reads issued AFTER those of `row` are still in flight (LDS returns in order), and make every later
+// use of the row's registers depend on the wait
+template <int N> GA_DEV void lds_rows_ready(f2 (&row)[5])
+{
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]) : "n"(N));
+}
+#endif
+
 template <int R> struct LgaPCfg {
   static constexpr int WS = 2 * R + 1;
   static constexpr int TW2 = LGA_TW + 2 * R;               // no alignment padding: a cell is 8 bytes wherever it is
@@ -612,6 +641,24 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_OUT 1
 #define GA_PP_SLOT PC::SLOT
 #define GA_PP_NDC ND
+#define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+// the same with the API-layout input staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
+#define GA_PP_NAME lga_apply_pp_xo
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 2
+#define GA_PP_OUT 1
+#define GA_PP_SLOT 512
+#define GA_PP_NDC 2
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
 #undef GA_PP_NAME
