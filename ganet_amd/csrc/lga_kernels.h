@@ -765,6 +765,18 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
 #undef GA_FG_GYP
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
+// the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
+#define GA_FG_NAME lga_filter_grad_pp_gypx
+#define GA_FG_XP 2
+#define GA_FG_GYP 1
+#define GA_FG_SLOT 512
+#define GA_FG_NDC 2
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)
