@@ -537,6 +537,9 @@ LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items)
   return mx;
 }
 
+#ifndef GA_LGA_PLANAR
+#define GA_LGA_PLANAR 1     // API-layout operands of the plane-pair kernels staged planar by 16-byte copies where W % 4 == 0
+#endif
 template <int R>
 int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H, int W,
                    bool transposed, hipStream_t st)
@@ -548,7 +551,14 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
       i64 items;
       const LgaSegMix mx = lga_items(W, H, B, D, false, &items);
       if (items < (1ll << 31)) {
-        if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
+        bool planar = false;
+        if constexpr (R == 2) planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);      // input staged by 16-byte copies
+        if constexpr (R == 2) {
+          if (planar && transposed) GA_LAUNCH((lga_apply_pp_x<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
+          else if (planar) GA_LAUNCH((lga_apply_pp_x<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
+        }
+        if (planar) {}
+        else if (transposed) GA_LAUNCH((lga_apply_pp<R, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
         else GA_LAUNCH((lga_apply_pp<R, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
         static const bool trace = getenv("GANET_TRACE_DISPATCH") != nullptr;      // (development: which LGA kernel ran)
         if (trace) fprintf(stderr, "[ganet] lga_apply_pp R=%d T=%d items=%lld: %d whole tiles + segments of %d planes x %d\n", R, (int)transposed, (long long)items, mx.n_whole, mx.sub_len, mx.nsub);
@@ -562,9 +572,6 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   return check_launch("lga apply");
 }
 
-#ifndef GA_LGA_PLANAR
-#define GA_LGA_PLANAR 1
-#endif
 // one LGA pass / data-backward with one side in the pair-interleaved layout (lga_apply_pp_pi / lga_apply_pp_po / lga_apply_pp_xo)
 int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, bool transposed, bool x_paired,
                       hipStream_t st)
@@ -620,7 +627,12 @@ int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snor
       i64 items;
       const LgaSegMix sg = lga_items(W, H, B, D, true, &items);      // (the epilogue reduces over all of D: whole tiles only)
       if (items < (1ll << 31)) {
-        GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
+        bool planar = false;
+        if constexpr (R == 2) {
+          planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
+          if (planar) GA_LAUNCH((lga_apply_pp_x<2, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
+        }
+        if (!planar) GA_LAUNCH((lga_apply_pp<R, false, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, snorm, sdy);
         return check_launch("lga apply + regression epilogue (plane pairs)");
       }
     }
@@ -643,7 +655,12 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
       sg.nseg = 1; sg.seg_len = D;
       const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
       if (items < (1ll << 31)) {
-        GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        bool planar = false;
+        if constexpr (R == 2) {
+          planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
+          if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+        }
+        if (!planar) GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         return check_launch("lga filter grad (plane pairs)");
       }
     }

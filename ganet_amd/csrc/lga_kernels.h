@@ -632,6 +632,25 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #undef GA_PP_NDC
 #undef GA_PP_Y
 
+// API layout in and out, the input staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x; radius 2)
+#define GA_PP_NAME lga_apply_pp_x
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 2
+#define GA_PP_OUT 0
+#define GA_PP_SLOT 512
+#define GA_PP_NDC 2
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+
 #define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
 // API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
 #define GA_PP_NAME lga_apply_pp_po
@@ -741,6 +760,18 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 // x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
+// x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x; radius 2)
+#define GA_FG_NAME lga_filter_grad_pp_x
+#define GA_FG_XP 2
+#define GA_FG_GYP 0
+#define GA_FG_SLOT 512
+#define GA_FG_NDC 2
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_xp
 #define GA_FG_XP 1
 #define GA_FG_GYP 0

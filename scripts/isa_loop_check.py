@@ -5,7 +5,8 @@ import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = ["lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gyp", "lga_filter_grad_pp"]
+KERNELS = ["lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp_xo", "lga_apply_pp_x", "lga_apply_pp", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gypx",
+           "lga_filter_grad_pp_gyp", "lga_filter_grad_pp_x", "lga_filter_grad_pp"]
 
 
 def asm_text(path=None):
@@ -48,7 +49,7 @@ def main():
             scr = sum(v for k, v in ops.items() if k.startswith("scratch_"))
             valu = sum(v for k, v in ops.items() if k.startswith("v_"))
             print(f"{name:40s} loop@{a:5d}: {sum(ops.values()):4d} instr, {valu:4d} VALU ({ops.get('v_pk_fma_f32', 0)} pk_fma, {ops.get('v_pk_mul_f32', 0)} pk_mul)  "
-                  f"{ops.get('ds_read_b64', 0):3d} ds_read_b64  {sum(v for k, v in ops.items() if 'load_lds' in k):3d} lds-dma  "
+                  f"{ops.get('ds_read_b64', 0) + ops.get('ds_read2_b32', 0):3d} ds_read_b64 / ds_read2_b32  {sum(v for k, v in ops.items() if 'load_lds' in k):3d} lds-dma  "
                   f"{ops.get('s_waitcnt', 0):3d} waits  scratch-in-loop {scr}" + ("   <-- UNSAFE" if scr else ""))
             bad += scr > 0
     sys.exit(1 if bad else 0)
