@@ -133,7 +133,12 @@ def test_lga_golden(api, dev, name):
 
 
 @pytest.mark.parametrize("shape,r,passes", [((1, 193, 24, 72), 2, 2), ((2, 33, 41, 67), 2, 1), ((1, 7, 64, 128), 1, 3),
-                                            ((1, 12, 19, 33), 3, 1), ((2, 3, 17, 9, 40), 2, 2)])
+                                            ((1, 12, 19, 33), 3, 1), ((2, 3, 17, 9, 40), 2, 2),
+                                            # W % 4 == 0, radius 2: the API-layout operands are staged planar by 16-byte copies and read
+                                            # with ds_read2_b32 (a path the CPU emulator does not execute) -- images narrower than a tile
+                                            # and than its staged row, odd and even depth, one to three passes
+                                            ((1, 9, 5, 8), 2, 2), ((2, 7, 9, 12), 2, 2), ((1, 1, 1, 4), 2, 1), ((1, 4, 3, 36), 2, 3),
+                                            ((1, 2, 67, 100), 2, 1)])
 def test_lga_random_vs_oracle(api, dev, port_oracle, shape, r, passes):
     rng = np.random.default_rng(sum(shape) + r)
     fs = list(shape)

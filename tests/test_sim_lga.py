@@ -27,7 +27,9 @@ def test_lga_chain_matches_golden(sim, name):
 
 @pytest.mark.parametrize("shape,r", [((1, 9, 10, 34), 2), ((2, 5, 17, 33), 2), ((1, 4, 9, 40), 1),
                                      ((1, 6, 3, 70), 3), ((1, 1, 8, 32), 2), ((1, 13, 16, 64), 2),
-                                     ((1, 50, 5, 66), 2), ((1, 2, 2, 2), 2)])
+                                     ((1, 50, 5, 66), 2), ((1, 2, 2, 2), 2),
+                                     # W % 4 == 0: the input is staged planar by 16-byte copies -- images narrower than a tile and than its staged row
+                                     ((1, 3, 2, 4), 2), ((1, 5, 1, 8), 2), ((2, 7, 9, 12), 2), ((1, 1, 1, 4), 2), ((1, 2, 3, 16), 2), ((1, 9, 7, 36), 2)])
 def test_lga_single_pass_vs_oracle(sim, port_oracle, shape, r):
     """Shapes that cross tile borders and LDS stage boundaries, odd and even widths (both window parities)."""
     rng = np.random.default_rng(sum(shape) + r)
@@ -107,7 +109,8 @@ def test_lga_unsupported_radius(sim):
 
 
 @pytest.mark.parametrize("shape,r", [((1, 11, 5, 34), 2), ((2, 6, 3, 68), 2), ((1, 7, 4, 40), 1), ((1, 1, 3, 32), 2),
-                                     ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2)])
+                                     ((1, 2, 5, 7), 2), ((1, 26, 2, 35), 2),
+                                     ((1, 3, 2, 4), 2), ((1, 5, 1, 8), 2), ((2, 7, 9, 12), 2), ((1, 1, 1, 4), 2), ((1, 2, 3, 16), 2)])    # (planar staging, narrow images)
 def test_plane_pair_filter_gradient(sim, port_oracle, shape, r):
     """lga_filter_grad_pp: odd and even D (a last pair with one real plane), more pairs than ring slots, accumulate mode
     through a two-pass chain."""
@@ -222,7 +225,8 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, mode):
 
 
 @pytest.mark.parametrize("mix", [1, 3, 0])
-@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2), (1, 47, 2, 100)])
+@pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2), (1, 47, 2, 100),
+                                   (1, 3, 2, 4), (1, 5, 1, 8), (2, 7, 9, 12), (1, 1, 1, 4), (1, 2, 3, 16)])      # (planar staging of the API-layout operands, narrow images)
 def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape, mix):
     """The call sequence of Lga2Function (default; GANET_LGA_PAIRED=0 switches it off) (ganet_amd/functions/GANet.py: _LgaChain): forward
     x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 (interleaved) = gX(gy); gf += gF(x, g_t1); gx = gX(g_t1)."""
