@@ -7,7 +7,8 @@ from ganet_amd import build
 
 HOT = ["sga_col_fwdILi5ELb1ELb1", "sga_col_bwdgILi5ELb0ELb1", "sga_row_fwdILi5ELi32ELi4ELi1ELb0ELb1",
        "sga_row_bwdgILi5ELi32ELi4ELi1ELb0", "sga_bwd_pointILi4ELb0", "sga_merge_px4", "lga_apply_ppILi2", "lga_apply_pp_piILi2",
-       "lga_apply_pp_poILi2", "lga_filter_grad_ppILi2", "lga_filter_grad_pp_xpILi2", "lga_filter_grad_pp_gypILi2",
+       "lga_apply_pp_poILi2", "lga_apply_pp_xoILi2", "lga_apply_pp_xILi2", "lga_filter_grad_ppILi2", "lga_filter_grad_pp_xpILi2", "lga_filter_grad_pp_gypILi2",
+       "lga_filter_grad_pp_gypxILi2", "lga_filter_grad_pp_xILi2", "sga_row_fwdILi2ELi32ELi4ELi1ELb0ELb0ELi64", "sga_row_bwdgILi2ELi32ELi4ELi1ELb0ELb0ELi64",
        "lga_filter_gradILi2", "lga_applyILi2ELb0"]
 print("static instruction counts per kernel (whole kernel body, all paths; gfx950, hipcc -O3; the row-forward kernels are\n"
       "compiled with -fno-slp-vectorize, see ganet_amd/build.py)\n")
