@@ -28,15 +28,21 @@ void launch_row_fwd(const float *x, const float *g, float *A, int S, int D, int 
   const size_t smem = row_smem_fwd(D);
   const dim3 grid((S * H + ROW_LN_F - 1) / ROW_LN_F), block(64);
 #if GA_ROW_GD64
-  // the depths the models use, with the depth axis over the whole wavefront: 33 and 48 at one, 65 at two disparities per lane
+  // D <= 72 with the depth axis over the whole wavefront: one disparity per lane up to 64, two up to 72
 #define L64(P, DESC, F, NP) GA_LAUNCH_SMEM((sga_row_fwd<P, ROW_SBH_F, ROW_PAD_F, 1, DESC, F, 64, NP>), grid, block, smem, st, x, g, A, geo)
-  if (ROW_LN_F == 1 && D <= 40) { if (dir == 3) L64(1, true, true, 5); else L64(1, false, true, 5); return; }
-  if (ROW_LN_F == 1 && D <= 48) { if (dir == 3) L64(1, true, true, 6); else L64(1, false, true, 6); return; }
-  if (ROW_LN_F == 1 && D > 64 && D <= 72) {
-    if (D % 2 == 0) { if (dir == 3) L64(2, true, true, 9); else L64(2, false, true, 9); }
-    else { if (dir == 3) L64(2, true, false, 9); else L64(2, false, false, 9); }
-    return;
+  // (NP = staged pieces per lane = ceil(D_max / 8) of the range: the models' 33 / 48 / 65 get exactly what they need, the ranges
+  //  in between share an instantiation)
+#define L64_1(NP) { if (dir == 3) L64(1, true, true, NP); else L64(1, false, true, NP); return; }
+#define L64_2(NP) { if (D % 2 == 0) { if (dir == 3) L64(2, true, true, NP); else L64(2, false, true, NP); }     \
+                    else { if (dir == 3) L64(2, true, false, NP); else L64(2, false, false, NP); } return; }
+  if (ROW_LN_F == 1) {
+    if (D <= 40) L64_1(5)
+    if (D <= 48) L64_1(6)
+    if (D <= 64) L64_1(8)
+    if (D <= 72) L64_2(9)      // (12 / 16 pieces for D <= 96 / 128 spill at these register caps: those depths keep the 16-lane kernels)
   }
+#undef L64_1
+#undef L64_2
 #undef L64
 #endif
 #define X(P)                                                                                        \
@@ -64,15 +70,19 @@ void launch_row_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, co
   const bool full = dpl > 0 && D % dpl == 0;
 #define L(P, DESC, F) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, ROW_LN_B, DESC, F>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir)
 #if GA_ROW_BWDG_GD64
-  // the depths the models use, with the depth axis over the whole wavefront: 33 and 48 at one, 65 at two disparities per lane
+  // D <= 72 with the depth axis over the whole wavefront: one disparity per lane up to 64, two up to 72
 #define L64(P, DESC, F, NP) GA_LAUNCH_SMEM((sga_row_bwdg<P, ROW_SBH_B, ROW_PAD_B, 1, DESC, F, 64, NP>), grid, block, smem, st, g, mask, kp, gout, G, geo, dir)
-  if (ROW_LN_B == 1 && D <= 40) { if (dir == 2) L64(1, true, true, 5); else L64(1, false, true, 5); return; }
-  if (ROW_LN_B == 1 && D <= 48) { if (dir == 2) L64(1, true, true, 6); else L64(1, false, true, 6); return; }
-  if (ROW_LN_B == 1 && D > 64 && D <= 72) {
-    if (D % 2 == 0) { if (dir == 2) L64(2, true, true, 9); else L64(2, false, true, 9); }
-    else { if (dir == 2) L64(2, true, false, 9); else L64(2, false, false, 9); }
-    return;
+#define L64_1(NP) { if (dir == 2) L64(1, true, true, NP); else L64(1, false, true, NP); return; }
+#define L64_2(NP) { if (D % 2 == 0) { if (dir == 2) L64(2, true, true, NP); else L64(2, false, true, NP); }     \
+                    else { if (dir == 2) L64(2, true, false, NP); else L64(2, false, false, NP); } return; }
+  if (ROW_LN_B == 1) {
+    if (D <= 40) L64_1(5)
+    if (D <= 48) L64_1(6)
+    if (D <= 64) L64_1(8)
+    if (D <= 72) L64_2(9)      // (12 / 16 pieces for D <= 96 / 128 spill at these register caps: those depths keep the 16-lane kernels)
   }
+#undef L64_1
+#undef L64_2
 #undef L64
 #endif
 #define X(P)                                                                                        \

@@ -104,9 +104,9 @@ def test_sga_random_vs_oracle(api, dev, port_oracle, shape):
 
 
 def test_sga_horizontal_depth_over_wavefront_boundaries(api, dev, port_oracle):
-    """Every boundary of the row kernels' dispatch between the wavefront-wide depth axis (D <= 40, D <= 48, 64 < D <= 72) and the
+    """Every boundary of the row kernels' dispatch between the wavefront-wide depth axis (D <= 40, 48, 64, 72) and the
     mirrored 16-lane DPP row (sga_row_tu.hip), rows of several batches with partial ones, forward bit-exact / gradients at 1e-4."""
-    for D in (1, 2, 39, 40, 41, 47, 49, 64, 66, 71, 72, 73):
+    for D in (1, 2, 39, 40, 41, 47, 49, 57, 64, 66, 71, 72, 73):
         shape = (1, 2, D, 3, 104)
         x, gs, go = pc.sga_inputs(shape, seed=100 + D)
         pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))

@@ -72,10 +72,10 @@ def test_horizontal_kernel_families(sim, port_oracle, shape, rowwave):
         sim.set_option("GANET_SGA_ROWWAVE", 1)
 
 
-@pytest.mark.parametrize("D", [1, 2, 39, 40, 41, 47, 49, 64, 66, 71, 72, 73])
+@pytest.mark.parametrize("D", [1, 2, 39, 40, 41, 47, 49, 57, 64, 66, 71, 72, 73])
 def test_horizontal_depth_over_wavefront_boundaries(sim, port_oracle, D):
     """The row kernels carry the depth axis over the whole wavefront for D <= 40 (1 disparity per lane, 5 staged pieces),
-    D <= 48 (1, 6) and 64 < D <= 72 (2, 9; even D: lanes wholly inside / outside) and in one mirrored 16-lane DPP row otherwise
+    D <= 48 (1, 6), D <= 64 (1, 8) and D <= 72 (2, 9; even D: lanes wholly inside / outside) and in one mirrored 16-lane DPP row otherwise
     (sga_row_tu.hip): every boundary of that dispatch, rows of two batches with a partial one, against the oracle."""
     shape = (1, 2, D, 2, 40)
     x, gs, go = pc.sga_inputs(shape, seed=100 + D)
