@@ -52,10 +52,12 @@ GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 #if defined(GA_HIPSIM)
 #define GA_KEEP_F2(v) ((void)0)
 #define GA_OPAQUE_S(v) ((void)0)
+#define GA_OPAQUE_V(v) ((void)0)
 #define GA_SCHED_FENCE() ((void)0)
 #else
 #define GA_KEEP_F2(v) asm volatile("" : "+v"(v))
 #define GA_OPAQUE_S(v) asm volatile("" : "+s"(v))   // uniform value the optimiser may not reason about
+#define GA_OPAQUE_V(v) asm volatile("" : "+v"(v))   // the same for a per-lane value
 // nothing is scheduled across this point: used to pin a hand-chosen instruction interleaving
 #if defined(GA_NO_SCHED_FENCE)
 #define GA_SCHED_FENCE() ((void)0)

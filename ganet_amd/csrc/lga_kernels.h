@@ -390,6 +390,9 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_NR
 #define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
 #endif
+#ifndef LGAP_ROW_ASM
+#define LGAP_ROW_ASM 1           // radius 2: a window row's 15 packed FMAs as one asm statement (lga_row_fma); 0 = one statement per FMA
+#endif
 #ifndef LGAP_ABLATE
 #define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs
 #endif
@@ -431,6 +434,24 @@ template <int R> struct LgaPCfg {
   static constexpr int SLOT = NDMA * 64;                   // floats per slot: every lane of every copy owns a dword
 };
 
+// M0 holds the LDS base of an LDS-DMA copy.  It is a RESERVED register: hipcc never allocates it, and the only code of its own
+// that reads it (LDS-DMA builtins, s_movrel / dynamic register indexing, GWS, s_sendmsg) sets it immediately before the use, so
+// a kernel without such constructs need not preserve it around the hand-written copies.  scripts/isa_loop_check.py asserts
+// that no instruction outside the copy batches touches m0 in these kernels.  GA_M0_SAVE = 1 restores the save / restore pair
+// (two scalar instructions per batch; the march is bound by its instruction count, profiles/r5c_* ... r5f_*).
+#ifndef GA_M0_SAVE
+#define GA_M0_SAVE 0
+#endif
+#if GA_M0_SAVE
+#define GA_M0_SAVE_ASM "s_mov_b32 %0, m0\n\t"
+#define GA_M0_RESTORE_ASM "\n\ts_mov_b32 m0, %0"
+#define GA_M0_RESTORE_TAIL "s_mov_b32 m0, %0"
+#else
+#define GA_M0_SAVE_ASM "; (m0 not preserved) %0\n\t"
+#define GA_M0_RESTORE_ASM ""
+#define GA_M0_RESTORE_TAIL ""
+#endif
+
 // one 4-byte global -> LDS copy per lane, 64-bit per-lane address: lane l's dword lands at slot + 4 * l
 GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
 {
@@ -440,7 +461,7 @@ GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" GA_M0_RESTORE_ASM
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 #endif
 }
@@ -474,6 +495,95 @@ template <int HALF> GA_DEV f2 mul2_bcast(f2 X, f2 W)
 #endif
 }
 
+// ---- one window ROW of the plane-pair forward / data-backward (5 x 5 window) as ONE asm statement ---------------------------
+// The 15 packed FMAs of a window row -- 5 taps x (E_m, O_{m-1}, O_m), see above -- in one statement.  Why: a v_pk_*_f32 result
+// needs one wait state before a dependent VALU read, and hipcc's hazard recogniser cannot see into inline asm: between two asm
+// statements of which the second reads a register the first wrote it inserts `s_nop 0` even when a dozen other asm statements
+// lie in between (it counts them as zero wait states).  With one statement per FMA that was 19 s_nop per plane pair, 12 % of
+// the steady body's instructions, in kernels that are bound by what a wave ISSUES, of any kind; inside one statement the order
+// below keeps dependent FMAs six instructions apart and none is needed.
+//   Taps of the row LAST column first (its LDS read is issued last: one wait covers the row).  Column bb uses weight half
+//   (P + bb) & 1 of pair (P + bb) >> 1 of the three pairs the caller passes for a slab, P = parity of the row's first tap index:
+//   slab -1 (tap 5a + bb, chain c) and slab +1 (50 + 5a + bb, chain p): P = a & 1; slab 0 (25 + 5a + bb, chain e): P = ~a & 1.
+//   Taps alternate between two accumulator chains (n = 5a + b2, b2 = 4 - bb); (e1, p1, c1) = the chain of the row's first tap.
+//   FIRST (row 0): the first two taps start the chains with v_pk_mul_f32.  WAIT >= 0: the statement begins with
+//   s_waitcnt lgkmcnt(WAIT) -- the counted wait that belongs to the planar staging's asm ds_read2_b32 (see lds_rows_ready).
+// The three op tables below were generated from that rule (the GA_HIPSIM branch restates it in plain C; both are held to the
+// oracle by tests/test_sim_lga.py and tests/test_gpu_parity.py).
+template <bool A_ODD, bool FIRST, int WAIT>
+GA_DEV void lga_row_fma(f2 &e1, f2 &p1, f2 &c1, f2 &e2, f2 &p2, f2 &c2, const f2 (&X)[5], const f2 *We, const f2 *Wp, const f2 *Wc)
+{
+#if defined(GA_HIPSIM)
+  const int Pe = A_ODD ? 0 : 1, Pp = A_ODD ? 1 : 0, Pc = Pp;
+  f2 *acc[2][3] = {{&e1, &p1, &c1}, {&e2, &p2, &c2}};
+  const f2 *W[3] = {We, Wp, Wc};
+  const int P[3] = {Pe, Pp, Pc};
+  for (int b2 = 0; b2 < 5; b2++) {
+    const int bb = 4 - b2;
+    for (int s3 = 0; s3 < 3; s3++) {
+      const f2 wp = W[s3][(P[s3] + bb) >> 1];
+      const float w = ((P[s3] + bb) & 1) ? wp.y : wp.x;
+      f2 &a = *acc[b2 & 1][s3];
+      if (FIRST && b2 < 2) a = mk2(X[bb].x * w, X[bb].y * w);
+      else a = fma2(X[bb], mk2(w, w), a);
+    }
+  }
+#else
+#define GA_RF_FMA0(acc, x, w) "v_pk_fma_f32 %" #acc ", %" #x ", %" #w ", %" #acc " op_sel_hi:[1,0,1]\n\t"
+#define GA_RF_FMA1(acc, x, w) "v_pk_fma_f32 %" #acc ", %" #x ", %" #w ", %" #acc " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define GA_RF_MUL0(acc, x, w) "v_pk_mul_f32 %" #acc ", %" #x ", %" #w " op_sel_hi:[1,0]\n\t"
+#define GA_RF_MUL1(acc, x, w) "v_pk_mul_f32 %" #acc ", %" #x ", %" #w " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+// operands: 0..2 = e1 p1 c1, 3..5 = e2 p2 c2, 6..10 = X[0..4], 11..13 = We[0..2], 14..16 = Wp[0..2], 17..19 = Wc[0..2], 20 = WAIT
+#define GA_RF_ROW_EVEN \
+  GA_RF_FMA1(0, 10, 13) GA_RF_FMA0(1, 10, 16) GA_RF_FMA0(2, 10, 19) \
+  GA_RF_FMA0(3, 9, 13) GA_RF_FMA1(4, 9, 15) GA_RF_FMA1(5, 9, 18) \
+  GA_RF_FMA1(0, 8, 12) GA_RF_FMA0(1, 8, 15) GA_RF_FMA0(2, 8, 18) \
+  GA_RF_FMA0(3, 7, 12) GA_RF_FMA1(4, 7, 14) GA_RF_FMA1(5, 7, 17) \
+  GA_RF_FMA1(0, 6, 11) GA_RF_FMA0(1, 6, 14) GA_RF_FMA0(2, 6, 17)
+#define GA_RF_ROW_ODD \
+  GA_RF_FMA0(0, 10, 13) GA_RF_FMA1(1, 10, 16) GA_RF_FMA1(2, 10, 19) \
+  GA_RF_FMA1(3, 9, 12) GA_RF_FMA0(4, 9, 16) GA_RF_FMA0(5, 9, 19) \
+  GA_RF_FMA0(0, 8, 12) GA_RF_FMA1(1, 8, 15) GA_RF_FMA1(2, 8, 18) \
+  GA_RF_FMA1(3, 7, 11) GA_RF_FMA0(4, 7, 15) GA_RF_FMA0(5, 7, 18) \
+  GA_RF_FMA0(0, 6, 11) GA_RF_FMA1(1, 6, 14) GA_RF_FMA1(2, 6, 17)
+#define GA_RF_ROW_FIRST \
+  GA_RF_MUL1(0, 10, 13) GA_RF_MUL0(1, 10, 16) GA_RF_MUL0(2, 10, 19) \
+  GA_RF_MUL0(3, 9, 13) GA_RF_MUL1(4, 9, 15) GA_RF_MUL1(5, 9, 18) \
+  GA_RF_FMA1(0, 8, 12) GA_RF_FMA0(1, 8, 15) GA_RF_FMA0(2, 8, 18) \
+  GA_RF_FMA0(3, 7, 12) GA_RF_FMA1(4, 7, 14) GA_RF_FMA1(5, 7, 17) \
+  GA_RF_FMA1(0, 6, 11) GA_RF_FMA0(1, 6, 14) GA_RF_FMA0(2, 6, 17)
+#define GA_RF_IN "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(X[4]), "v"(We[0]), "v"(We[1]), "v"(We[2]), "v"(Wp[0]), "v"(Wp[1]), \
+                 "v"(Wp[2]), "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "n"(WAIT >= 0 ? WAIT : 0)
+  static_assert(!(FIRST && A_ODD), "the pair's first row is row 0");
+  // (volatile only where the statement carries the wait: the wait orders it against the asm LDS reads, which the compiler
+  // cannot see as producers of X)
+  if constexpr (FIRST) {
+    if constexpr (WAIT >= 0)
+      asm volatile("s_waitcnt lgkmcnt(%20)\n\t" GA_RF_ROW_FIRST : "=&v"(e1), "=&v"(p1), "=&v"(c1), "=&v"(e2), "=&v"(p2), "=&v"(c2) : GA_RF_IN);
+    else
+      asm(GA_RF_ROW_FIRST : "=&v"(e1), "=&v"(p1), "=&v"(c1), "=&v"(e2), "=&v"(p2), "=&v"(c2) : GA_RF_IN);
+  } else if constexpr (A_ODD) {
+    if constexpr (WAIT >= 0)
+      asm volatile("s_waitcnt lgkmcnt(%20)\n\t" GA_RF_ROW_ODD : "+v"(e1), "+v"(p1), "+v"(c1), "+v"(e2), "+v"(p2), "+v"(c2) : GA_RF_IN);
+    else
+      asm(GA_RF_ROW_ODD : "+v"(e1), "+v"(p1), "+v"(c1), "+v"(e2), "+v"(p2), "+v"(c2) : GA_RF_IN);
+  } else {
+    if constexpr (WAIT >= 0)
+      asm volatile("s_waitcnt lgkmcnt(%20)\n\t" GA_RF_ROW_EVEN : "+v"(e1), "+v"(p1), "+v"(c1), "+v"(e2), "+v"(p2), "+v"(c2) : GA_RF_IN);
+    else
+      asm(GA_RF_ROW_EVEN : "+v"(e1), "+v"(p1), "+v"(c1), "+v"(e2), "+v"(p2), "+v"(c2) : GA_RF_IN);
+  }
+#undef GA_RF_IN
+#undef GA_RF_ROW_EVEN
+#undef GA_RF_ROW_ODD
+#undef GA_RF_ROW_FIRST
+#undef GA_RF_FMA0
+#undef GA_RF_FMA1
+#undef GA_RF_MUL0
+#undef GA_RF_MUL1
+#endif
+}
+
 // all ND copies of one plane pair: copy k moves lane l's dword from base + off[k] (bytes) to slot + 256 k + 4 l, scalar base +
 // 32-bit lane offset (the offsets are the same for every pair, only the base moves).  M0 holds the LDS base of the batch and
 // is saved / restored around it (a write to M0 needs one wait state before the copy that uses it).
@@ -503,17 +613,17 @@ template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&
   unsigned keep;
   static_assert(ND == 5 || ND == 7 || ND == 10, "copy batch written out for R = 1, 2, 3");
   if constexpr (ND == 5)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
-                 GA_PP_COPY(7, 1024) "s_mov_b32 m0, %0"
+    asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+                 GA_PP_COPY(7, 1024) GA_M0_RESTORE_TAIL
                  : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]) : "memory", "scc");
   else if constexpr (ND == 7)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
-                 GA_PP_COPY(7, 1024) GA_PP_COPY(8, 1280) GA_PP_COPY(9, 1536) "s_mov_b32 m0, %0"
+    asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+                 GA_PP_COPY(7, 1024) GA_PP_COPY(8, 1280) GA_PP_COPY(9, 1536) GA_M0_RESTORE_TAIL
                  : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]) : "memory", "scc");
   else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
+    asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\t" GA_PP_COPY(3, 0) GA_PP_COPY(4, 256) GA_PP_COPY(5, 512) GA_PP_COPY(6, 768)
                  GA_PP_COPY(7, 1024) GA_PP_COPY(8, 1280) GA_PP_COPY(9, 1536) GA_PP_COPY(10, 1792) GA_PP_COPY(11, 2048) GA_PP_COPY(12, 2304)
-                 "s_mov_b32 m0, %0"
+                 GA_M0_RESTORE_TAIL
                  : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]),
                    "v"(o[8]), "v"(o[9]) : "memory", "scc");
 #endif
@@ -531,26 +641,46 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
   // every address = (uniform tap-plane pointer) + (32-bit per-lane pixel offset): scalar base + one offset register per
   // distinct neighbour instead of a 64-bit address per load
   const unsigned pix32 = (unsigned)(ic * geo.W + jc);
-  auto tap = [&](int t) -> float {
+  // in-image test of tap (a, bb) as an all-ones / zero word: row mask AND column mask, ten per-lane words for a border tile
+  // instead of 75 predicates (which do not fit the scalar registers); an AND with such a word is not a select the optimiser
+  // could sink a load under
+  int mrow[WS], mcol[WS];
+#pragma unroll
+  for (int k = 0; k < WS; k++) {
+    mrow[k] = (!CHECK || (ic + k - R >= 0 && ic + k - R < geo.H)) ? -1 : 0;
+    mcol[k] = (!CHECK || (jc + k - R >= 0 && jc + k - R < geo.W)) ? -1 : 0;
+  }
+  auto ok_mask = [&](int a, int bb) { return CHECK ? (mrow[a + R] & mcol[bb + R]) : -1; };
+  // the pixel's OWN tap t feeds the three sums (and, untransposed, is the weight); loads are unconditional and masked with AND
+  // (a load under a condition costs an s_waitcnt vmcnt(0) each)
+  auto own_tap = [&](int t) -> float {
     const int dd = t / K, a = (t % K) / WS - R, bb = t % WS - R;
-    bool ok = true;
-    if (CHECK) {
-      const int i2 = ic + a, j2 = jc + bb;
-      ok = i2 >= 0 && i2 < geo.H && j2 >= 0 && j2 < geo.W;
-    }
-    float own = 0.f;
-    if (CHECK || !TRANSPOSED || dd != 1) own = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)t * geo.HW + pix32);   // interior gX needs own taps only for the d-edge sums
-    float wv = own;
-    if (TRANSPOSED) {
-      // unconditional load, value masked below (a load under a condition costs an s_waitcnt vmcnt(0) each)
-      const int tf = (2 - dd) * K + (-a + R) * WS + (-bb + R);
-      const int noff = ok ? a * geo.W + bb : 0;
-      wv = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)tf * geo.HW + (unsigned)((int)pix32 + noff));
-    }
-    const int okm = ok ? -1 : 0;
+    const float own = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)t * geo.HW + pix32);
+    const int okm = ok_mask(a, bb);
     cmid += i2f(f2i(own) & ~okm);
     if (dd == 0) sin_m += i2f(f2i(own) & okm);
     if (dd == 2) sin_p += i2f(f2i(own) & okm);
+    return i2f(f2i(own) & okm);
+  };
+  if (TRANSPOSED) {
+    // Two sweeps, so that at most ~75 loads are in flight with the 76 weight registers not yet live in the first: (1) the own
+    // taps, reduced to the three sums as they arrive (an interior pixel needs only the two outer slabs: its centre
+    // coefficient is zero); (2) the weights proper, tap (-dd, -a, -b) of the neighbour at (+a, +b).  In one sweep the ~125
+    // destinations plus the weights exceed the 168 registers of three waves per SIMD (13 - 21 spill operations per lane).
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (CHECK || t / K != 1) (void)own_tap(t);
+      if (CHECK && (t + 1) % K == 0) GA_SCHED_FENCE();      // (border tiles: one depth slab of loads in flight at a time)
+    }
+    GA_SCHED_FENCE();
+  }
+  auto tap = [&](int t) -> float {
+    if (!TRANSPOSED) return own_tap(t);
+    const int dd = t / K, a = (t % K) / WS - R, bb = t % WS - R;
+    const int okm = ok_mask(a, bb);
+    const int tf = (2 - dd) * K + (-a + R) * WS + (-bb + R);
+    const int noff = (a * geo.W + bb) & okm;              // (own pixel where the neighbour is outside the image, value dropped)
+    const float wv = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)tf * geo.HW + (unsigned)((int)pix32 + noff));
     return i2f(f2i(wv) & okm);
   };
 #pragma unroll
@@ -558,7 +688,7 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
     const float lo = tap(t);
     const float hi = t + 1 < NT ? tap(t + 1) : 0.f;
     wq[t >> 1] = mk2(lo, hi);
-    if ((t + 2) % K < 2) GA_SCHED_FENCE();            // (about once per depth slab)
+    if ((!TRANSPOSED || CHECK) && (t + 2) % K < 2) GA_SCHED_FENCE();            // (about once per depth slab)
   }
 }
 
@@ -574,9 +704,9 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+  asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %3, %2 offset:0\n\tglobal_load_lds_dwordx4 %4, %2 offset:1024\n\t"
-               "s_mov_b32 m0, %0"
+               GA_M0_RESTORE_TAIL
                : "=&s"(keep) : "s"(dst), "s"(base), "v"(o[0]), "v"(o[1]) : "memory", "scc");
 #endif
 }
@@ -717,7 +847,7 @@ GA_DEV void lga_dma4s(const float *base, unsigned off, float *slot, int lane)
   (void)lane;
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %3, %2\n\ts_mov_b32 m0, %0"
+  asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %3, %2" GA_M0_RESTORE_ASM
                : "=&s"(keep) : "s"(dst), "s"(base), "v"(off) : "memory");
 #endif
 }
@@ -732,6 +862,43 @@ template <int HALF> GA_DEV f2 fma2_xbcast(f2 X, f2 G, f2 acc)
   if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(X), "v"(G));
   else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(X), "v"(G));
   return acc;
+#endif
+}
+
+// one window ROW of the plane-pair filter gradient (5 x 5 window) as ONE asm statement, for the reason given at lga_row_fma:
+//   P[bb] += (X.x, X.x) * Ga;  Q[bb] += X * Gc;  then  P[bb] += (X.y, X.y) * (Gn.y, Gn.x)   (the two updates of a P five
+//   instructions apart), last column first.  Gn = (g[2q+1], g[2q+2]) as the gy ring holds it: the multiplier of the odd plane,
+//   (g[2q+2], g[2q+1]), is Gn with its halves swapped by op_sel.
+// WAIT >= 0: preceded by s_waitcnt lgkmcnt(WAIT), the counted wait of the planar staging's asm LDS reads.
+template <int WAIT>
+GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn, f2 Gc)
+{
+#if defined(GA_HIPSIM)
+  for (int b2 = 0; b2 < 5; b2++) {
+    const int bb = 4 - b2;
+    Pr[bb] = fma2(mk2(X[bb].x, X[bb].x), Ga, Pr[bb]);
+    Qr[bb] = fma2(X[bb], Gc, Qr[bb]);
+  }
+  for (int b2 = 0; b2 < 5; b2++) {
+    const int bb = 4 - b2;
+    Pr[bb] = fma2(mk2(X[bb].y, X[bb].y), mk2(Gn.y, Gn.x), Pr[bb]);
+  }
+#else
+// operands: 0..4 = P[0..4], 5..9 = Q[0..4], 10..14 = X[0..4], 15 = Ga, 16 = Gn, 17 = Gc, 18 = WAIT
+#define GA_FG_PX(p, x) "v_pk_fma_f32 %" #p ", %" #x ", %15, %" #p " op_sel_hi:[0,1,1]\n\t"
+#define GA_FG_PY(p, x) "v_pk_fma_f32 %" #p ", %" #x ", %16, %" #p " op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+#define GA_FG_Q(q, x) "v_pk_fma_f32 %" #q ", %" #x ", %17, %" #q "\n\t"
+#define GA_FG_ROW GA_FG_PX(4, 14) GA_FG_Q(9, 14) GA_FG_PX(3, 13) GA_FG_Q(8, 13) GA_FG_PX(2, 12) GA_FG_Q(7, 12) GA_FG_PX(1, 11) GA_FG_Q(6, 11) \
+                  GA_FG_PX(0, 10) GA_FG_Q(5, 10) GA_FG_PY(4, 14) GA_FG_PY(3, 13) GA_FG_PY(2, 12) GA_FG_PY(1, 11) GA_FG_PY(0, 10)
+#define GA_FG_OPS : "+v"(Pr[0]), "+v"(Pr[1]), "+v"(Pr[2]), "+v"(Pr[3]), "+v"(Pr[4]), "+v"(Qr[0]), "+v"(Qr[1]), "+v"(Qr[2]), "+v"(Qr[3]), "+v"(Qr[4]) \
+                   : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]), "v"(X[4]), "v"(Ga), "v"(Gn), "v"(Gc), "n"(WAIT >= 0 ? WAIT : 0)
+  if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%18)\n\t" GA_FG_ROW GA_FG_OPS);
+  else asm(GA_FG_ROW GA_FG_OPS);
+#undef GA_FG_PX
+#undef GA_FG_PY
+#undef GA_FG_Q
+#undef GA_FG_ROW
+#undef GA_FG_OPS
 #endif
 }
 

@@ -1,6 +1,8 @@
 """Static check of the hand-counted-vmcnt kernels: inside the main loop of each LDS-DMA kernel the compiler must not have added
 vector-memory operations of its own (register spills = scratch_load / scratch_store count in vmcnt and would silently break the
-explicit s_waitcnt vmcnt(n) bookkeeping).  python scripts/isa_loop_check.py [asm file]   (no GPU needed; exits 1 on a finding)"""
+explicit s_waitcnt vmcnt(n) bookkeeping).  Also: the copy batches set M0 without saving it (lga_kernels.h: GA_M0_SAVE), which is
+only sound while nothing else in the kernel reads or writes M0 -- every mention of m0 must be one of the batches' own
+`s_mov_b32 m0, <sgpr>` / `s_add_u32 m0, m0, ...`.  python scripts/isa_loop_check.py [asm file]   (no GPU needed; exits 1 on a finding)"""
 import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +31,12 @@ def main():
             continue
         end = next(j for j in range(i, len(lines)) if "s_endpgm" in lines[j])
         body = lines[i:end]
+        foreign_m0 = [bl.strip() for bl in body if re.search(r"\bm0\b", bl.split(";")[0])
+                      and not re.match(r"\s*(s_mov_b32 m0, s\d+|s_add_u32 m0, m0, )", bl)]
+        if foreign_m0:
+            nm = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.split("(")[0].replace("void ga::", "")
+            print(f"{nm:40s} m0 touched outside the copy batches: {foreign_m0[:3]}   <-- UNSAFE")
+            bad += 1
         labels = {mm.group(1): k for k, bl in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", bl)] if mm}
         loops = []
         for k, bl in enumerate(body):
