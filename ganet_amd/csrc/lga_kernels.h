@@ -394,7 +394,7 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #define LGAP_ROW_ASM 1           // radius 2: a window row's 15 packed FMAs as one asm statement (lga_row_fma); 0 = one statement per FMA
 #endif
 #ifndef LGAP_ABLATE
-#define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs
+#define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs, 4 no tap gather
 #endif
 // Two dwords of one LDS row pair in ONE instruction, into a register pair: p[O0] and p[O1] (dword offsets, at most 255).  The
 // planar staging of lga_apply_pp.inc (GA_PP_IN = 2) keeps the two planes of a pair LGA_TW + 8 dwords apart; written as two

@@ -15,6 +15,9 @@
 //     computed and land in LDS after it, so the memory latency hides behind the compute.
 // Arithmetic (fwd_step / bwdg_step) is shared with sga_kernels.h: bit-exact forward.
 #pragma once
+#ifndef GA_COL_TILED_ABLATE
+#define GA_COL_TILED_ABLATE 0      // development only (timing): bit 0 the column scans write their result tiled, bit 1 the adjoint reads its mask tiled
+#endif
 #include "ga_common.h"
 #include "sga_kernels.h"
 

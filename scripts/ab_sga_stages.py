@@ -1,0 +1,14 @@
+"""Same-box SGA stage timings (bench.stage_timings: the four scans of a pass in sequence, merge / per-pixel kernel) for several
+builds of the library: python scripts/ab_sga_stages.py libA.so libB.so ...  (timing-only ablation builds included: their
+results are not checked here)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, bench
+from ganet_amd import _native
+for rep in range(2):
+    for name in sys.argv[1:]:
+        _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name))
+        inp = bench.make_inputs(torch.device("cuda:0"))
+        st = bench.stage_timings(inp, iters=10)
+        print(name, {k: round(v, 4) for k, v in st.items() if k.startswith("sga")}, flush=True)
