@@ -98,13 +98,17 @@ def one_step_two_streams(inp, side):
     return g1, g2
 
 
-def stage_timings(inp, iters=5):
-    """Per-stage device time (ms) with HIP events on the launch stream, via the C ABI."""
+def stage_timings(inp, iters=5, only=None):
+    """Device time (ms) of EVERY kernel of a step, measured in place: the step's 16 launches issued through the C ABI in the
+    order the autograd Functions issue them, a HIP event between consecutive launches on the launch stream, `iters` passes.
+    (A kernel repeated on its own sees its inputs cached from its previous run -- with the non-temporal result stores a scan
+    repeated alone runs 30 % faster than inside the step, an LGA pass ~12 % -- and a "whole call minus its scans" difference
+    adds the biases of both sides; the interval between two events holds one kernel and one launch gap, which is what the
+    kernel trace of the same command shows as well: profiles/*kernel_stats_in_step.csv.)"""
     from ganet_amd import _native
     lib = _native.lib()
     x, gs, go, xl, f, gy = [t.detach() if torch.is_tensor(t) else [u.detach() for u in t] for t in inp]
     N, C, D, H, W = x.shape
-    n = x.numel()
     st = torch.cuda.current_stream().cuda_stream
     A = torch.empty((4,) + tuple(x.shape), device=x.device)
     out = torch.empty_like(x)
@@ -114,81 +118,55 @@ def stage_timings(inp, iters=5):
     gx = torch.empty_like(x)
     gw = [torch.empty_like(g) for g in gs]
     B, DL, HL, WL = xl.shape
-    t1, y, gt1, gxl = (torch.empty_like(xl) for _ in range(4))
+    y, gxl = torch.empty_like(xl), torch.empty_like(xl)
     gf = torch.empty_like(f)
-
-    def timed(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / iters
-
-    def timed_sequence(fns):
-        """The calls of `fns` back to back, as they follow each other inside the op, with an event between them: per-call
-        time IN SEQUENCE (a call repeated on its own sees its input cached from its previous run -- with the non-temporal
-        result stores a scan repeated alone runs 30 % faster than the same scan inside the step)."""
-        for fn in fns:
-            fn()
-        torch.cuda.synchronize()
-        acc = [0.0] * len(fns)
-        for _ in range(iters):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)]
-            ev[0].record()
-            for i, fn in enumerate(fns):
-                fn()
-                ev[i + 1].record()
-            ev[-1].synchronize()
-            for i in range(len(fns)):
-                acc[i] += ev[i].elapsed_time(ev[i + 1])
-        return [a / iters for a in acc]
-
-    res = {}
-    names = ["down", "up", "right", "left"]
-    ts = timed_sequence([lambda d=d: lib.call("ganet_sga_scan_forward", x.data_ptr(), gs[d].data_ptr(), A[d].data_ptr(),
-                                              N, C, D, H, W, d, st) for d in range(4)])
-    for d in range(4):
-        res[f"sga_scan_fwd_{names[d]}"] = ts[d]
-    res["sga_forward_call"] = timed(lambda: lib.call(
-        "ganet_sga_forward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), out.data_ptr(),
-        mask.data_ptr(), kp.data_ptr(), N, C, D, H, W, st))
-    res["sga_merge_argmax"] = res["sga_forward_call"] - sum(res[f"sga_scan_fwd_{n}"] for n in names)
-    npix = N * C * H * W
-    ts = timed_sequence([lambda d=d: lib.call("ganet_sga_backward_scan", gs[d].data_ptr(), mask.data_ptr(),
-                                              kp.data_ptr() + 2 * d * npix, go.data_ptr(), G[d].data_ptr(), N, C, D, H, W, d, st)
-                         for d in range(4)])
-    for d in range(4):
-        res[f"sga_bwd_scan_{names[d]}"] = ts[d]
-    res["sga_backward_call"] = timed(lambda: lib.call(
-        "ganet_sga_backward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), mask.data_ptr(),
-        kp.data_ptr(), go.data_ptr(), G.data_ptr(), gx.data_ptr(), *[g.data_ptr() for g in gw],
-        N, C, D, H, W, st))
-    res["sga_bwd_point"] = res["sga_backward_call"] - sum(res[f"sga_bwd_scan_{n}"] for n in names)
     # LGA2 as Lga2Function runs it: the private intermediate and its gradient pair-interleaved (functions/GANet.py: _LgaChain)
     tp = torch.empty(B * ((DL + 1) // 2) * HL * WL * 2, device=xl.device)
     gtp = torch.empty_like(tp)
     p = lambda t: t.data_ptr()      # noqa: E731
-
-    def lga2_fwd():
-        lib.call("ganet_lga_apply_paired", p(xl), p(f), p(tp), B, DL, HL, WL, RADIUS, 0, 0, 1, st)
-        lib.call("ganet_lga_apply_paired", p(tp), p(f), p(y), B, DL, HL, WL, RADIUS, 0, 1, 0, st)
-
-    def lga2_bwd():
-        lib.call("ganet_lga_filter_grad_paired", p(tp), p(gy), p(gf), B, DL, HL, WL, RADIUS, 0, 1, 0, st)
-        lib.call("ganet_lga_apply_paired", p(gy), p(f), p(gtp), B, DL, HL, WL, RADIUS, 1, 0, 1, st)
-        lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)
-        lib.call("ganet_lga_apply_paired", p(gtp), p(f), p(gxl), B, DL, HL, WL, RADIUS, 1, 1, 0, st)
-    res["lga_fwd_pass"] = timed(lga2_fwd) / 2                # average of the two passes of the chain
-    res["lga_bwd_pass"] = timed(lga2_bwd) / 2                # (filter gradient + data-backward) x 2
-    # one pass on the API layout (LgaFunction, the last pass of DispAggTail): for comparison with earlier rounds
-    res["lga_fwd_pass_api_layout"] = timed(lambda: lib.call(
-        "ganet_lga_forward", p(xl), p(f), p(t1), B, DL, HL, WL, RADIUS, st))
-    res["lga_bwd_pass_api_layout"] = timed(lambda: lib.call(
-        "ganet_lga_backward", p(xl), p(f), p(gy), p(gxl), p(gf), B, DL, HL, WL, RADIUS, 0, st))
+    npix = N * C * H * W
+    names = ["down", "up", "right", "left"]
+    gp = [p(g) for g in gs]
+    calls = []
+    for d in range(4):
+        calls.append((f"sga_scan_fwd_{names[d]}", lambda d=d: lib.call("ganet_sga_scan_forward", p(x), gp[d], p(A[d]), N, C, D, H, W, d, st)))
+    calls.append(("sga_merge_argmax", lambda: lib.call("ganet_sga_merge", p(A), p(out), p(mask), p(kp), N, C, D, H, W, st)))
+    for d in range(4):
+        calls.append((f"sga_bwd_scan_{names[d]}", lambda d=d: lib.call("ganet_sga_backward_scan", gp[d], p(mask), p(kp) + 2 * d * npix,
+                                                                      p(go), p(G[d]), N, C, D, H, W, d, st)))
+    calls.append(("sga_bwd_point", lambda: lib.call("ganet_sga_backward_point", p(x), *gp, p(A), p(G), p(gx), *[p(t) for t in gw],
+                                                    N, C, D, H, W, st)))
+    calls += [
+        ("lga_fwd_apply_1", lambda: lib.call("ganet_lga_apply_paired", p(xl), p(f), p(tp), B, DL, HL, WL, RADIUS, 0, 0, 1, st)),
+        ("lga_fwd_apply_2", lambda: lib.call("ganet_lga_apply_paired", p(tp), p(f), p(y), B, DL, HL, WL, RADIUS, 0, 1, 0, st)),
+        ("lga_bwd_filter_grad_2", lambda: lib.call("ganet_lga_filter_grad_paired", p(tp), p(gy), p(gf), B, DL, HL, WL, RADIUS, 0, 1, 0, st)),
+        ("lga_bwd_data_2", lambda: lib.call("ganet_lga_apply_paired", p(gy), p(f), p(gtp), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
+        ("lga_bwd_filter_grad_1", lambda: lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
+        ("lga_bwd_data_1", lambda: lib.call("ganet_lga_apply_paired", p(gtp), p(f), p(gxl), B, DL, HL, WL, RADIUS, 1, 1, 0, st)),
+    ]
+    if only is not None:          # (development A/B scripts: one op's kernels, e.g. with a library build that lacks the newer entries)
+        calls = [c for c in calls if c[0].startswith(only)]
+    for _ in range(2):
+        for _, fn in calls:
+            fn()
+    torch.cuda.synchronize()
+    acc = [0.0] * len(calls)
+    for _ in range(iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(calls) + 1)]
+        ev[0].record()
+        for i, (_, fn) in enumerate(calls):
+            fn()
+            ev[i + 1].record()
+        ev[-1].synchronize()
+        for i in range(len(calls)):
+            acc[i] += ev[i].elapsed_time(ev[i + 1])
+    res = {name: a / iters for (name, _), a in zip(calls, acc)}
+    res["step_sum_of_kernels"] = sum(res.values())
+    if only is not None and only != "lga":
+        return res
+    # per PASS, as earlier rounds reported the LGA2 chain (mean of its two passes)
+    res["lga_fwd_pass"] = (res["lga_fwd_apply_1"] + res["lga_fwd_apply_2"]) / 2
+    res["lga_bwd_pass"] = (res["lga_bwd_filter_grad_2"] + res["lga_bwd_data_2"] + res["lga_bwd_filter_grad_1"] + res["lga_bwd_data_1"]) / 2
     return res
 
 
@@ -207,6 +185,19 @@ _FAMILY_KERNELS = {
 
 
 FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak
+# what this chip was MEASURED to reach with the access patterns / instruction streams these kernels can use (micro-benchmarks
+# under scripts/ubench, results in profiles/): the spec peaks above stay the denominators of every `frac`
+ACHIEVABLE = {"hbm_copy_GBs": 6300.0, "hbm_4in_1out_marching_GBs": 5000.0, "hbm_linear_fill_GBs": 4400.0,
+              "fp32_pk_fma_TFLOPs": 134.0,
+              "source": "profiles/r3b_mall_bw.txt, scripts/ubench/stream_patterns.hip, profiles/r2a_ubench_valu_rate.txt"}
+# north_star: "(for LGA) MFMA utilisation reported against gfx950 peak".  The LGA contraction is [D x 25] . [25 x 3] per PIXEL with both
+# operands private to the pixel: an MFMA tile would carry N = 3 useful columns of 16 / 32, and the one fp32 shape that fits,
+# v_mfma_f32_4x4x1_16B_f32, was measured at 77 - 90 TFLOP/s alone against 134 for v_pk_fma_f32 (mixing the two is slower than
+# either): the kernels use the packed VALU and no MFMA instruction, so MFMA utilisation is 0 by construction.
+MFMA_NOTE = {"used": False, "mfma_utilisation": 0.0, "fp32_mfma_peak_TFLOPs": FP32_PEAK_TFLOPS,
+             "f32_4x4x1_measured_TFLOPs": [77.0, 90.0], "pk_fma_measured_TFLOPs": 134.0,
+             "why": "per-pixel [D x 25].[25 x 3]: N = 3 of an MFMA tile's 16/32 columns; packed fp32 VALU is the faster unit",
+             "source": "profiles/r2a_ubench_valu_rate.txt, DESIGN.md section 3.3"}
 _LGA_PASS_FLOPS = 2.0 * 75 * 193 * 240 * 624      # 75 FMAs per output element, one apply or one filter-gradient pass
 _FAMILY_FLOPS = {"lga_apply (fwd pass)": _LGA_PASS_FLOPS, "lga_apply+filter_grad (bwd pass)": 2 * _LGA_PASS_FLOPS}
 
@@ -249,6 +240,7 @@ def roofline_from_stages(stages):
         "sga_merge_argmax": (["sga_merge_argmax"], _V, 1),
         "sga_bwd_scan": ([k for k in stages if k.startswith("sga_bwd_scan_")], _V / 4, 1),
         "sga_bwd_point": (["sga_bwd_point"], 2 * _V + 8 * _G, 1),
+        # an LGA "launch" of a family = one PASS: forward one apply kernel, backward filter gradient + data-backward
         "lga_apply+filter_grad (bwd pass)": (["lga_bwd_pass"], ALG_BYTES["lga2_bwd"] / 2, 2),
         "lga_apply (fwd pass)": (["lga_fwd_pass"], ALG_BYTES["lga2_fwd"] / 2, 2),
     }
@@ -292,6 +284,10 @@ def roofline_from_stages(stages):
     if unit_traffic is not None:
         out["unit_traffic_bytes"] = int(unit_traffic)
         out["unit_traffic_ratio"] = round(unit_traffic / UNIT_BYTES, 3)
+    out["timing"] = ("every kernel of the step timed in place (HIP events between consecutive launches of one in-order pass over "
+                     "the step's 16 launches): stage_ms; no family is a difference of other measurements")
+    out["mfma"] = MFMA_NOTE
+    out["achievable"] = ACHIEVABLE
     return out
 
 
@@ -364,9 +360,16 @@ def stub_main(args):
             "unit": "steps/sec", "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "stub"}
-    probe = gdist.allreduce_probe(ctx, "gloo", torch.device("cpu"), nelem=1 << 16, iters=2)
+    if ctx.rank == 0:
+        print("[bench] measured: " + json.dumps(line), file=sys.stderr, flush=True)
+    # the protocol test's stand-in for the RCCL probe of the real run: same code path (child processes, own rendezvous), gloo
+    delay = float(os.environ.get("GANET_BENCH_TEST_DELAY_RANK0", "0"))
+    if delay and ctx.rank == 0:
+        time.sleep(delay)
+    probe = gdist.allreduce_probe_isolated(ctx, "gloo", 0, timeout_s=float(os.environ.get("GANET_BENCH_PROBE_TIMEOUT", "150")),
+                                           nelem=1 << 16, iters=2)
     if probe is not None:
-        line["rccl"] = probe              # (the protocol test's stand-in for the RCCL probe of the real run)
+        line["rccl"] = probe
     gdist.finish(ctx)
     if ctx.rank == 0:
         print(json.dumps(line))
@@ -488,6 +491,18 @@ def main():
         "unit_hbm_frac": round(value / ctx.world_size * UNIT_BYTES / (HBM_PEAK_GBS * 1e9), 4),
     }
     if ctx.rank == 0:
+        # the measured value is on record before anything else runs (stderr; the ONE stdout line comes last)
+        print("[bench] measured: " + json.dumps(line), file=sys.stderr, flush=True)
+    if ctx.world_size > 1:
+        # The gradient all-reduce of a data-parallel caller (26.3 MB fp32 = GANet-deep's parameters) over RCCL / xGMI: AFTER the
+        # timed region, BEFORE rank 0's extra measurements (ranks 1..N-1 never sit in a collective with a timeout while rank 0
+        # is busy), on every rank, in child processes of their own (gdist.allreduce_probe_isolated: a hung or failed RCCL call
+        # cannot take the benchmark's processes or its measured value with it).  Never part of `value`.
+        delay = float(os.environ.get("GANET_BENCH_TEST_DELAY_RANK0", "0"))       # tests: rank 0 arrives late at the probe
+        if delay and ctx.rank == 0:
+            time.sleep(delay)
+        line["rccl"] = gdist.allreduce_probe_isolated(ctx, os.environ.get("GANET_BENCH_COLLECTIVE", "nccl"), device.index)
+    if ctx.rank == 0:
         if graph is not None:
             # for reference: the same step launched eagerly from Python (host-speed dependent)
             torch.cuda.synchronize()
@@ -533,19 +548,6 @@ def main():
                 line["two_stream_ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 4)
             except Exception as e:
                 line["two_stream_ms_per_step"] = f"failed: {type(e).__name__}: {e}"
-    if ctx.world_size > 1:
-        # The gradient all-reduce of a data-parallel caller (26.3 MB fp32 = GANet-deep's parameters) over RCCL / xGMI, AFTER
-        # the timed region and on every rank; an extra object, never part of `value` (the op metric has no collective).
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)                      # (RCCL / gloo may print on stdout)
-        try:
-            probe = gdist.allreduce_probe(ctx, os.environ.get("GANET_BENCH_COLLECTIVE", "nccl"), device)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
-        line["rccl"] = probe
     gdist.finish(ctx)
     if ctx.rank == 0:
         print(json.dumps(line))

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -26,6 +26,8 @@ _PROTOS = {
     "ganet_sga_forward_infer": [_P] * 9 + [_I] * 5 + [_P],
     "ganet_sga_forward_infer_scratch": [_P] * 6 + [_I] * 5,
     "ganet_sga_backward_scan": [_P] * 5 + [_I] * 6 + [_P],
+    "ganet_sga_merge": [_P] * 4 + [_I] * 5 + [_P],
+    "ganet_sga_backward_point": [_P] * 12 + [_I] * 5 + [_P],
     "ganet_sga_backward_dir": [_P] * 9 + [_I] * 7 + [_P],
     "ganet_sga_backward": [_P] * 15 + [_I] * 5 + [_P],
     "ganet_sga_forward_compat": [_P] * 8 + [_I] * 5 + [_P],
@@ -69,7 +71,9 @@ E_INVALID, E_UNSUPPORTED, E_RUNTIME = -1, -2, -3
 class CApi:
     """Thin, typed view of one loaded libganet_*.so."""
 
-    def __init__(self, path):
+    def __init__(self, path, strict=True):
+        """strict=False (development A/B scripts only): bind what an OLDER build of the library exports and skip the ABI
+        version check, so that last round's kernels can be timed beside this round's on one box."""
         if not os.path.exists(path):
             raise GanetError(
                 f"{path} not found: build the HIP extension first "
@@ -79,11 +83,16 @@ class CApi:
         self._lib.ganet_last_error.restype = ctypes.c_char_p
         self._lib.ganet_last_error.argtypes = []
         for name, args in _PROTOS.items():
-            fn = getattr(self._lib, name)
+            try:
+                fn = getattr(self._lib, name)
+            except AttributeError:
+                if strict:
+                    raise
+                continue
             fn.argtypes = args
             fn.restype = _I
         got = self._lib.ganet_abi_version()
-        if got != ABI_VERSION:
+        if got != ABI_VERSION and strict:
             raise GanetError(f"{path}: ABI version {got}, expected {ABI_VERSION}")
         self.is_simulator = bool(self._lib.ganet_is_simulator())
 

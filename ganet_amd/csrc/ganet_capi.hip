@@ -738,8 +738,24 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
   else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;
+  else if (!strcmp(name, "HIPSIM_LATE_LDS")) hipsim::S().late_lds = value != 0;
+  else if (!strcmp(name, "HIPSIM_LGKM_SLACK")) hipsim::S().lgkm_slack = value;     // tests: every counted LDS wait loosened by `value`
+  else if (!strcmp(name, "HIPSIM_VMCNT_SLACK")) hipsim::S().vm_slack = value;      // tests: every counted copy wait loosened by `value`
 #endif
-  else return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
+  else {
+    // names retired in ABI 7 (their kernels were removed or became the only path): accepted and ignored, so that a caller
+    // written against ABI 6 keeps running; one note per process
+    static const char *const retired[] = {"GANET_LGA_BWD_STREAMS", "GANET_LGA_FG_WPS", "GANET_LGA_SPLIT", "GANET_LGA_VMCNT_SAFE",
+                                          "GANET_SGA_BLOCK_H", "GANET_SGA_BLOCK_V", "GANET_SGA_GD", "GANET_SGA_GD_H", "GANET_SGA_GD_V",
+                                          "GANET_SGA_INFER_FUSED", "GANET_SGA_MERGE4", "GANET_SGA_POINT_BLOCK", "GANET_SGA_STREAMS"};
+    for (const char *r : retired)
+      if (!strcmp(name, r)) {
+        static std::atomic<int> noted{0};
+        if (!noted.exchange(1)) fprintf(stderr, "[ganet] ganet_set_option: %s is retired (no effect); see INTEGRATION.md\n", name);
+        return GANET_OK;
+      }
+    return fail(GANET_E_INVALID, "ganet_set_option: unknown option %s", name);
+  }
   return GANET_OK;
 }
 
@@ -752,20 +768,15 @@ GA_EXPORT int ganet_sga_scan_forward(const float *x, const float *g, float *A, i
   return scan_fwd(x, g, A, N, C, D, H, W, dir, (hipStream_t)stream);
 }
 
-GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
-                                const float *g3, float *A_ws, float *out, uint8_t *mask,
-                                uint16_t *kp, int N, int C, int D, int H, int W, void *stream)
+GA_EXPORT int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint16_t *kp, int N, int C, int D, int H, int W,
+                               void *stream)
 {
-  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out || !mask || !kp)
-    return fail(GANET_E_INVALID, "ganet_sga_forward: null pointer");
-  GA_TRY(check_dims5("ganet_sga_forward", N, C, D, H, W));
-  if (D > 65535) return fail(GANET_E_UNSUPPORTED, "ganet_sga_forward: D > 65535");
+  if (!A_ws || !out || !mask || !kp) return fail(GANET_E_INVALID, "ganet_sga_merge: null pointer");
+  GA_TRY(check_dims5("ganet_sga_merge", N, C, D, H, W));
+  if (D > 65535) return fail(GANET_E_UNSUPPORTED, "ganet_sga_merge: D > 65535");
   const i64 n = (i64)N * C * D * H * W;
   const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
-  const float *gs[4] = {g0, g1, g2, g3};
-  // (the four scans on four streams were measured twice and dropped: 0.596 vs 0.606 ms, DESIGN.md section 7)
-  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   const i64 HWl = (i64)H * W;
   if (HWl % 4 == 0 && aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) &&
       (((uintptr_t)kp & 7) == 0) && npix / 4 / 64 + 1 < (1ll << 31)) {
@@ -776,6 +787,22 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   GA_LAUNCH((sga_merge_px<uint8_t>), dim3(px_grid(npix)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
             A_ws + 3 * n, out, mask, kp, D, HWl, npix);
   return check_launch("sga merge");
+}
+
+GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
+                                const float *g3, float *A_ws, float *out, uint8_t *mask,
+                                uint16_t *kp, int N, int C, int D, int H, int W, void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !out || !mask || !kp)
+    return fail(GANET_E_INVALID, "ganet_sga_forward: null pointer");
+  GA_TRY(check_dims5("ganet_sga_forward", N, C, D, H, W));
+  if (D > 65535) return fail(GANET_E_UNSUPPORTED, "ganet_sga_forward: D > 65535");
+  const i64 n = (i64)N * C * D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const float *gs[4] = {g0, g1, g2, g3};
+  // (the four scans on four streams were measured twice and dropped: 0.596 vs 0.606 ms, DESIGN.md section 7)
+  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
+  return ganet_sga_merge(A_ws, out, mask, kp, N, C, D, H, W, stream);
 }
 
 namespace {
@@ -859,6 +886,23 @@ GA_EXPORT int ganet_sga_backward_dir(const float *x, const float *g, const float
   return bwd_point(x, grad_x, pa, 1, N, C, D, H, W, accumulate ? 1 : 0, st);
 }
 
+GA_EXPORT int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
+                                        const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1, float *gw2,
+                                        float *gw3, int N, int C, int D, int H, int W, void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !G_ws || !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
+    return fail(GANET_E_INVALID, "ganet_sga_backward_point: null pointer");
+  GA_TRY(check_dims5("ganet_sga_backward_point", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  const float *gs[4] = {g0, g1, g2, g3};
+  float *gws[4] = {gw0, gw1, gw2, gw3};
+  PointArgs pa = {};
+  for (int d = 0; d < 4; d++) {
+    pa.G[d] = G_ws + d * n; pa.A[d] = A_ws + d * n; pa.g[d] = gs[d]; pa.gw[d] = gws[d]; pa.dir[d] = d;
+  }
+  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, (hipStream_t)stream);
+}
+
 GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
                                  const float *g3, const float *A_ws, const uint8_t *mask,
                                  const uint16_t *kp, const float *grad_out, float *G_ws,
@@ -874,12 +918,10 @@ GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   float *gws[4] = {gw0, gw1, gw2, gw3};
-  PointArgs pa = {};
-  for (int d = 0; d < 4; d++) {
+  for (int d = 0; d < 4; d++)
     GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st));
-    pa.G[d] = G_ws + d * n; pa.A[d] = A_ws + d * n; pa.g[d] = gs[d]; pa.gw[d] = gws[d]; pa.dir[d] = d;
-  }
-  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, st);
+  (void)gws;
+  return ganet_sga_backward_point(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, stream);
 }
 
 GA_EXPORT int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1,

@@ -360,7 +360,7 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 // copy model (tests/hipsim/hipsim.h)
 #if defined(GA_HIPSIM)
 #define GA_VMCNT(n) hipsim::vmcnt(n)
-#define GA_LGKMCNT0() ((void)0)
+#define GA_LGKMCNT0() hipsim::lgkmcnt(0)
 #define GA_DMA_MASKED(n) hipsim::dma_masked(n)
 #else
 #define GA_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -401,21 +401,10 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 // loads hipcc pairs up neighbouring COLUMNS instead and assembles the plane pairs with 32 v_mov per plane pair.  The asm is
 // invisible to the compiler's wait insertion: lds_rows_ready() below is the counted wait that goes with it.
 #if !defined(GA_HIPSIM)
-template <int O0, int O1> GA_DEV f2 lds_read2_b32(lds_cptr p)
+template <int O0, int O1> GA_DEV void lds_read2_b32(f2 &r, lds_cptr p)
 {
   static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2_b32 offsets are 8 bits");
-  f2 r;
   asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(p), "n"(O0), "n"(O1));
-  return r;
-}
-// the five cells of window row TROW (0, 1, 2) relative to `p`, planes PLD dwords apart, rows ROWF dwords apart
-template <int TROW, int ROWF, int PLD> GA_DEV void lds_read2_row5(f2 (&row)[5], lds_cptr p)
-{
-  row[0] = lds_read2_b32<TROW * ROWF + 0, TROW * ROWF + 0 + PLD>(p);
-  row[1] = lds_read2_b32<TROW * ROWF + 1, TROW * ROWF + 1 + PLD>(p);
-  row[2] = lds_read2_b32<TROW * ROWF + 2, TROW * ROWF + 2 + PLD>(p);
-  row[3] = lds_read2_b32<TROW * ROWF + 3, TROW * ROWF + 3 + PLD>(p);
-  row[4] = lds_read2_b32<TROW * ROWF + 4, TROW * ROWF + 4 + PLD>(p);
 }
 // wait until at most N LDS reads issued AFTER those of `row` are still in flight (LDS returns in order), and make every later
 // use of the row's registers depend on the wait
@@ -423,7 +412,20 @@ template <int N> GA_DEV void lds_rows_ready(f2 (&row)[5])
 {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]) : "n"(N));
 }
+#else
+// emulator: the read lands in `r` when a counted wait of the lane covers it (tests/hipsim/hipsim.h: late_lds)
+template <int O0, int O1> GA_DEV void lds_read2_b32(f2 &r, lds_cptr p) { hipsim::lds_read2(&r.x, p + O0, p + O1); }
+template <int N> GA_DEV void lds_rows_ready(f2 (&)[5]) { hipsim::lgkmcnt(N); }
 #endif
+// the five cells of window row TROW (0, 1, 2) relative to `p`, planes PLD dwords apart, rows ROWF dwords apart
+template <int TROW, int ROWF, int PLD> GA_DEV void lds_read2_row5(f2 (&row)[5], lds_cptr p)
+{
+  lds_read2_b32<TROW * ROWF + 0, TROW * ROWF + 0 + PLD>(row[0], p);
+  lds_read2_b32<TROW * ROWF + 1, TROW * ROWF + 1 + PLD>(row[1], p);
+  lds_read2_b32<TROW * ROWF + 2, TROW * ROWF + 2 + PLD>(row[2], p);
+  lds_read2_b32<TROW * ROWF + 3, TROW * ROWF + 3 + PLD>(row[3], p);
+  lds_read2_b32<TROW * ROWF + 4, TROW * ROWF + 4 + PLD>(row[4], p);
+}
 
 template <int R> struct LgaPCfg {
   static constexpr int WS = 2 * R + 1;
@@ -514,6 +516,7 @@ template <bool A_ODD, bool FIRST, int WAIT>
 GA_DEV void lga_row_fma(f2 &e1, f2 &p1, f2 &c1, f2 &e2, f2 &p2, f2 &c2, const f2 (&X)[5], const f2 *We, const f2 *Wp, const f2 *Wc)
 {
 #if defined(GA_HIPSIM)
+  if (WAIT >= 0) hipsim::lgkmcnt(WAIT);
   const int Pe = A_ODD ? 0 : 1, Pp = A_ODD ? 1 : 0, Pc = Pp;
   f2 *acc[2][3] = {{&e1, &p1, &c1}, {&e2, &p2, &c2}};
   const f2 *W[3] = {We, Wp, Wc};
@@ -874,6 +877,7 @@ template <int WAIT>
 GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn, f2 Gc)
 {
 #if defined(GA_HIPSIM)
+  if (WAIT >= 0) hipsim::lgkmcnt(WAIT);
   for (int b2 = 0; b2 < 5; b2++) {
     const int bb = 4 - b2;
     Pr[bb] = fma2(mk2(X[bb].x, X[bb].x), Ga, Pr[bb]);

@@ -321,6 +321,10 @@ GA_DEV void bwdg_step(const float (&go)[DPL], const MaskT (&mk)[DPL], float (&Gn
 #pragma unroll
       for (int i = 0; i < DPL; i++) {
         const float up = i < DPL - 1 ? Gn[i + 1] : hi;
+        // (an outside lane stays 0 because its neighbour term is MULTIPLIED by w3 = 0, not selected away -- one instruction less
+        // per position in kernels that are bound by their instruction count.  Finite gradients only: 0 * Inf would put a NaN into
+        // the outside lane, from where it returns through `hi`; the reference propagates a non-finite gradient through the whole
+        // scanline as well (every term of its recurrence is a product with it), so nothing finite is lost.  ADVICE r3.)
         const float dn = i > 0 ? Gn[i - 1] : lo;
         float t = G[i];
         t = fmaf(Gn[i], wn[1], t);

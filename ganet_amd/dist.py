@@ -151,6 +151,95 @@ def allreduce_probe(ctx, backend, device, nelem=GRAD_ELEMS_GANET_DEEP, iters=10,
         return {"backend": backend, "ranks": ctx.world_size, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def allreduce_probe_isolated(ctx, backend, device_index, timeout_s=150.0, nelem=GRAD_ELEMS_GANET_DEEP, iters=10):
+    """allreduce_probe() in CHILD processes, one per rank, on a rendezvous of their own (a fresh port chosen by rank 0 and
+    handed round over the caller's group).  Why not in-process: a collective that hangs does not become an error string -- the
+    device sync blocks and RCCL's watchdog aborts the process after its timeout -- and a failure on ONE rank (new_group, the
+    allocation) leaves the others waiting in the next collective; either way the benchmark's already measured value would be
+    lost or badly delayed.  Here every rank waits for its own child for at most `timeout_s`, kills exactly that child if it is
+    still alive (by pid), and returns; the caller's process group never sees the probe.  Every rank calls it; rank 0 gets the
+    child's JSON object (or {"error": ...}), the others None."""
+    import json
+    import subprocess
+    import sys
+    if ctx.world_size == 1:
+        return None
+    port = [_free_port() if ctx.rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port[0]), "RANK": str(ctx.rank), "WORLD_SIZE": str(ctx.world_size),
+                "LOCAL_RANK": str(ctx.local_rank)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC between the ranks' GPUs (the host driver has no legacy IPC)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)                                    # the child's rendezvous is a plain TCP store of its own
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "ganet_amd.dist", "--probe", backend, str(device_index), str(nelem), str(iters)]
+    res = {"backend": backend, "ranks": ctx.world_size}
+    try:
+        child = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            out, err = child.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            child.kill()                                    # (this child, by pid)
+            out, err = child.communicate()
+            res["error"] = f"probe child of rank {ctx.rank} still running after {timeout_s:.0f} s: killed"
+            out = ""
+        if "error" not in res:
+            line = next((ln for ln in reversed(out.strip().splitlines()) if ln.startswith("{")), None)
+            if line is not None:
+                res = json.loads(line)
+            elif ctx.rank == 0:
+                res["error"] = f"probe child exited with {child.returncode}: {(err or '').strip()[-300:]}"
+    except Exception as e:                                   # noqa: BLE001
+        res["error"] = f"{type(e).__name__}: {e}"[:300]
+    if ctx.rank != 0:
+        return None
+    res["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    res["isolated"] = "child processes, own rendezvous"
+    return res
+
+
+def _probe_main(argv):
+    """child of allreduce_probe_isolated: `python -m ganet_amd.dist --probe <backend> <device index> <nelem> <iters>`"""
+    import json
+    backend, dev_index, nelem, iters = argv[0], int(argv[1]), int(argv[2]), int(argv[3])
+    delay = float(os.environ.get("GANET_PROBE_TEST_DELAY_RANK0", "0"))      # tests: rank 0 arrives late
+    if delay and int(os.environ.get("RANK", "0")) == 0:
+        time.sleep(delay)
+    device = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(device)
+    try:
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]),
+                                timeout=datetime.timedelta(seconds=60))
+        # (local_rank = the device this rank computes on: max_over_ranks puts its scalar there under nccl)
+        ctx = DistCtx(int(os.environ["RANK"]), dev_index if backend == "nccl" else int(os.environ.get("LOCAL_RANK", "0")),
+                      int(os.environ["WORLD_SIZE"]), True)
+        res = allreduce_probe(ctx, backend, device, nelem=nelem, iters=iters)
+    except Exception as e:                                   # noqa: BLE001
+        res = {"backend": backend, "error": f"{type(e).__name__}: {e}"[:300]}
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(res), flush=True)
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:                                        # noqa: BLE001
+        pass
+
+
 def finish(ctx):
     if ctx.initialized_here and dist.is_initialized():
         dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 6 and sys.argv[1] == "--probe":
+        _probe_main(sys.argv[2:])

@@ -194,6 +194,11 @@ class _LgaChain(Function):
     def _bwd(ctx, gradOutput):
         filters, *ins = ctx.saved_tensors
         g = gradOutput.contiguous()
+        if getattr(ctx, "paired", False) and g.data_ptr() % 16 != 0:
+            # the pair-interleaved kernels stage the incoming gradient with 16-byte copies; the forward has already committed
+            # to the interleaved intermediate, so an odd storage offset (a contiguous slice of a larger buffer) gets a copy
+            # instead of an error
+            g = g.clone(memory_format=torch.contiguous_format)
         _check(g)
         B, D, H, W = _lga_dims(ins[0], filters, ctx.radius)
         if getattr(ctx, "paired", False):

@@ -73,7 +73,9 @@ def train_step(model, optimizer, name, left, right, target, max_disp, crit):
     optimizer.zero_grad()
     outputs = model(left, right)
     if int(nvalid) == 0:
-        loss = sum(o.sum() for o in outputs) * 0.0
+        # zero loss that still reaches every parameter; nan_to_num first: 0 * (a non-finite output) would be NaN and poison
+        # the all-reduced gradients of the ranks that do have valid pixels
+        loss = sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).sum() for o in outputs) * 0.0
         err = loss.detach()
     else:
         loss = loss_mix(name, outputs, target, mask, crit)

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 7
+#define GANET_ABI_VERSION 8
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -59,6 +59,12 @@ int ganet_sga_scan_forward(const float *x, const float *g, float *A,
 int ganet_sga_forward(const float *x, const float *g0, const float *g1, const float *g2,
                       const float *g3, float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
                       int N, int C, int D, int H, int W, void *stream);
+
+/* The last step of ganet_sga_forward on its own: out / mask / kp from the four directional volumes in A_ws (same buffers, same
+ * layouts).  ganet_sga_forward == 4 x ganet_sga_scan_forward + this; exported so that a caller (bench.py) can time it in place.
+ * Replaces: the three `Max` launches (GANet_kernel.cu:23-36, 964-994) and the four MaxDepth launches of the backward (:50-64). */
+int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
+                    int N, int C, int D, int H, int W, void *stream);
 
 /* Inference-only forward: out = relu(bn_scale[c] * max_dir A_dir + bn_shift[c]) (bn_scale = bn_shift = NULL:
  * plain max).  No mask / arg-max is produced; A_ws ([4][N*C*D*H*W]) is scratch and stays untouched when the scans can take
@@ -101,6 +107,13 @@ int ganet_sga_backward(const float *x, const float *g0, const float *g1, const f
                        const float *g3, const float *A_ws, const uint8_t *mask, const uint16_t *kp,
                        const float *grad_out, float *G_ws, float *grad_x, float *gw0, float *gw1,
                        float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
+
+/* The last step of ganet_sga_backward on its own: every gradient from the four adjoint volumes in G_ws (written by
+ * ganet_sga_backward_scan) and the forward volumes in A_ws.  ganet_sga_backward == 4 x ganet_sga_backward_scan + this.
+ * Replaces: the bottom_diff part of sga_*_data_backward (:182-207 & mirrors) + sga_*_weight_backward (:210-281 & mirrors). */
+int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
+                             const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1,
+                             float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
 
 /* Reference-compatible buffer contract, for callers that keep the reference's
  * libs/GANet/functions/GANet.py unchanged:

@@ -89,6 +89,18 @@ struct State {
   std::vector<std::deque<DmaOp>> dma;
   bool late_dma = false;
   long dma_late_landed = 0;
+  // LDS reads written in asm (ds_read2_b32 of the planar LGA staging): the compiler does not wait for those, the kernel's own
+  // counted s_waitcnt lgkmcnt(n) does.  late_lds: the destination registers hold a signalling pattern until a wait of the lane
+  // leaves at most n reads outstanding (the LDS queue of a wave returns in order), i.e. the data arrives as LATE as the
+  // kernel's waits permit; consuming a row before its wait, or a count one too loose, computes on NaNs.  Reads the compiler
+  // issues itself sit in the same hardware queue and can only make the real wait stricter than this model.
+  // *_slack: tests only -- every wait of that counter behaves as if its count were that much larger (a deliberately loosened
+  // wait must fail the parity tests).
+  struct LdsOp { float *dst; float v[2]; };
+  std::vector<std::deque<LdsOp>> lds;
+  bool late_lds = false;
+  long lds_late_landed = 0;
+  int lgkm_slack = 0, vm_slack = 0;
   // order in which the runnable threads of a block are resumed between two barriers: 0 = ascending thread index,
   // 1 = descending.  A hand-off through LDS that lacks a barrier is decided by whichever thread runs first; results that
   // are the same in both orders do not depend on that luck.
@@ -129,7 +141,25 @@ inline void vmcnt(int n)
   State &s = S();
   if (!s.late_dma) return;
   auto &q = s.dma[flat_tid()];
-  while ((int)q.size() > n) { dma_land(q.front()); q.pop_front(); s.dma_late_landed++; }
+  while ((int)q.size() > n + s.vm_slack) { dma_land(q.front()); q.pop_front(); s.dma_late_landed++; }
+}
+// one lane's ds_read2_b32 issued from asm: dst[0] = *p0, dst[1] = *p1, visible to the lane after its next covering wait
+inline void lds_read2(float *dst, const float *p0, const float *p1)
+{
+  State &s = S();
+  if (!s.late_lds) { dst[0] = *p0; dst[1] = *p1; return; }
+  State::LdsOp op;
+  op.dst = dst; op.v[0] = *p0; op.v[1] = *p1;      // (sampled at issue: the ring slot is not rewritten while reads of it are in flight)
+  dst[0] = dst[1] = __builtin_nanf("0x5152");
+  s.lds[flat_tid()].push_back(op);
+}
+// s_waitcnt lgkmcnt(n)
+inline void lgkmcnt(int n)
+{
+  State &s = S();
+  if (!s.late_lds) return;
+  auto &q = s.lds[flat_tid()];
+  while ((int)q.size() > n + s.lgkm_slack) { q.front().dst[0] = q.front().v[0]; q.front().dst[1] = q.front().v[1]; q.pop_front(); s.lds_late_landed++; }
 }
 
 inline int update_dpp(int old, int src, int ctrl)
@@ -172,11 +202,16 @@ inline void fiber_entry()
 {
   State &s = S();
   s.body();
+  if (s.late_dma && s.vm_slack > 0) {              // (loosened on purpose: the final wait leaves copies behind; let them land)
+    auto &q = s.dma[flat_tid()];
+    while (!q.empty()) { dma_land(q.front()); q.pop_front(); }
+  }
   if (s.late_dma && !s.dma[flat_tid()].empty()) {
     fprintf(stderr, "hipsim: thread %d ended with %d global->LDS copies in flight (its LDS may already belong to the next workgroup)\n",
             flat_tid(), (int)s.dma[flat_tid()].size());
     abort();
   }
+  if (s.late_lds) s.lds[flat_tid()].clear();      // (registers die with the thread)
   s.fibers[s.cur].done = true;
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
@@ -198,6 +233,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
   s.wave_bar.assign((nt + 63) / 64, Barrier());
   s.xchg.assign(nt, 0);
   s.dma.assign(nt, std::deque<State::DmaOp>());
+  s.lds.assign(nt, std::deque<State::LdsOp>());
   std::vector<char> smem(shmem + 64);
   s.dyn_smem = (char *)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
   for (unsigned bz = 0; bz < grid.z; bz++)

@@ -134,6 +134,28 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
         dev.sync()
         assert np.abs(dev.host(gw1) - dev.host(gw[d])).max() <= 1e-6
     assert np.abs(dev.host(gx1) - dev.host(gx)).max() <= 1e-5
+    if per_dir:
+        # ABI 8: the composite entries are their steps -- 4 x scan + ganet_sga_merge, 4 x adjoint scan +
+        # ganet_sga_backward_point -- bit for bit (bench.py times the steps in place)
+        A2, out2 = dev.empty((4,) + x.shape), dev.empty(x.shape)
+        mask2, kp2 = dev.empty(x.shape, np.uint8), dev.empty((4, N, C, H, W), np.uint16)
+        for d in range(4):
+            api.call("ganet_sga_scan_forward", dev.ptr(dx), dev.ptr(dg[d]), dev.ptr(A2) + 4 * d * x.size, N, C, D, H, W, d, dev.stream)
+        api.call("ganet_sga_merge", dev.ptr(A2), dev.ptr(out2), dev.ptr(mask2), dev.ptr(kp2), N, C, D, H, W, dev.stream)
+        dev.sync()
+        assert np.array_equal(dev.host(out2), dev.host(out)) and np.array_equal(dev.host(mask2), dev.host(mask))
+        assert np.array_equal(dev.host(kp2), dev.host(kp))
+        G2, gx2 = dev.empty((4,) + x.shape), dev.empty(x.shape)
+        gw2 = [dev.empty(gs[0].shape) for _ in range(4)]
+        for d in range(4):
+            api.call("ganet_sga_backward_scan", dev.ptr(dg[d]), dev.ptr(mask), dev.ptr(kp) + 2 * d * (N * C * H * W), dev.ptr(dgo),
+                     dev.ptr(G2) + 4 * d * x.size, N, C, D, H, W, d, dev.stream)
+        api.call("ganet_sga_backward_point", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(G2), dev.ptr(gx2),
+                 *[dev.ptr(g) for g in gw2], N, C, D, H, W, dev.stream)
+        dev.sync()
+        assert np.array_equal(dev.host(gx2), dev.host(gx))
+        for d in range(4):
+            assert np.array_equal(dev.host(gw2[d]), dev.host(gw[d]))
     err = {"gx": float(np.abs(dev.host(gx) - want["gx"]).max())}
     for d in range(4):
         err[f"gw{d}"] = float(np.abs(dev.host(gw[d]) - want[f"gw{d}"]).max())

@@ -97,6 +97,39 @@ def test_bench_gpus2_plumbing_with_stub_step(launcher):
     assert abs(probe["busbw_GBs"] - probe["algbw_GBs"]) <= 0.02 * probe["algbw_GBs"] + 0.01      # 2 (N-1)/N = 1 at N = 2
 
 
+def _run_stub_bench(extra_env, timeout=300):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_probe_survives_a_late_rank0():
+    """rank 0 reaches the all-reduce probe 10 s after rank 1 (it used to run its extra measurements first,
+    with the other ranks already inside a collective that has a timeout).  The probe runs in child processes on a rendezvous
+    of their own and before rank 0's extras: the late rank only makes the children's rendezvous wait."""
+    line, err = _run_stub_bench({"GANET_BENCH_TEST_DELAY_RANK0": "10"})
+    assert line["value"] > 0
+    assert "error" not in line["rccl"], line["rccl"]
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["result_ok"]
+    assert "[bench] measured:" in err            # the value was on record before the probe started
+
+
+def test_hung_probe_costs_the_line_nothing():
+    """a collective that never completes must not take the measured value with it.  Rank 0's probe child
+    sleeps past the parent's patience: the parent kills exactly that child, reports the error inside `rccl`, and the ONE JSON
+    line carries the value all the same."""
+    line, _ = _run_stub_bench({"GANET_PROBE_TEST_DELAY_RANK0": "120", "GANET_BENCH_PROBE_TIMEOUT": "8"}, timeout=200)
+    assert line["value"] > 0 and line["n_gpus"] == 2
+    assert "error" in line["rccl"] and "killed" in line["rccl"]["error"], line["rccl"]
+
+
 def _skip_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),

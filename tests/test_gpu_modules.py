@@ -190,6 +190,30 @@ def test_sga_on_16_byte_aligned_views(torch_mod, port_oracle, offset):
         assert np.abs(_np(got) - want).max() <= pc.TOL
 
 
+def test_lga2_backward_with_a_4_byte_aligned_gradient(torch_mod, port_oracle):
+    """Lga2Function's forward commits to the pair-interleaved private intermediate; an incoming gradient that is
+    contiguous but only 4-byte aligned (a slice at an odd element offset of a larger buffer) must still reach the kernels
+    (they stage it with 16-byte copies): the backward copies it instead of raising."""
+    torch = torch_mod
+    import torch.nn.functional as F
+    from ganet_amd.functions.GANet import Lga2Function
+    torch.manual_seed(5)
+    shape = (1, 9, 20, 40)
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    f = F.normalize(torch.randn(1, 75, 20, 40, device="cuda"), p=1, dim=1).requires_grad_()
+    buf = torch.empty(x.numel() + 8, device="cuda")
+    gy = buf[1:1 + x.numel()].view(shape)
+    gy.copy_(torch.randn(shape, device="cuda"))
+    assert gy.is_contiguous() and gy.data_ptr() % 16 != 0
+    y = Lga2Function.apply(x, f, 2)
+    gx, gf = torch.autograd.grad(y, [x, f], gy)
+    torch.cuda.synchronize()
+    o_y, ins = port_oracle.lga_chain_forward(_np(x), _np(f), 2, 2)
+    o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy), 2)
+    assert np.abs(_np(y) - o_y).max() <= pc.TOL
+    assert np.abs(_np(gx) - o_gx).max() <= pc.TOL and np.abs(_np(gf) - o_gf).max() <= pc.TOL
+
+
 @pytest.mark.parametrize("shape", [(1, 3, 33, 10, 24), (1, 2, 9, 5, 7), (1, 1, 240, 4, 12)])
 def test_sga_without_grad_takes_the_inference_path(torch_mod, port_oracle, shape):
     """Under torch.no_grad() (predict.py:113) or when no input needs a gradient, SgaFunction keeps nothing for a

@@ -109,6 +109,63 @@ def test_lga_counted_waits_with_late_landing_copies(sim, port_oracle, segs, mix,
         sim.set_option("GANET_LGA_MIX", 1)
 
 
+# ---- the planar staging's asm LDS reads (ds_read2_b32) and their counted lgkmcnt waits ---------------------------------------
+# the default LGA kernels for W % 4 == 0 read their window rows with ds_read2_b32 written in asm, which the
+# compiler does not wait for; the kernel's own s_waitcnt lgkmcnt(LA * 5) -- now the first instruction of the row's FMA statement
+# -- does.  HIPSIM_LATE_LDS: such a read lands in its registers only when a wait of the lane covers it (they hold NaNs until
+# then).  All shapes below have W % 4 == 0, i.e. run the planar instantiations (lga_apply_pp_x / _xo, lga_filter_grad_pp_x /
+# _gypx) of both call sequences, copies landing late as well.
+_PLANAR_SHAPES = [(1, D, 3, 36) for D in (1, 2, 3, 8, 9, 13, 14, 21, 26, 27)] + [(2, 13, 5, 68), (1, 22, 2, 8), (1, 15, 9, 40), (1, 33, 1, 4)]
+
+
+def _planar_chain(sim, port_oracle, shape, paired):
+    dev = pc.NumpyDev()
+    rng = np.random.default_rng(sum(shape))
+    B, D, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+    gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+    chain = pc.check_lga2_paired if paired else pc.check_lga_chain
+    return chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+
+
+@pytest.mark.parametrize("paired", [0, 1])
+def test_lga_planar_reads_with_late_landing_lds(sim, port_oracle, paired):
+    sim.set_option("HIPSIM_LATE_LDS", 1)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        for shape in _PLANAR_SHAPES:
+            err = _planar_chain(sim, port_oracle, shape, paired)
+            assert max(err.values()) < 5e-5, (shape, err)
+    finally:
+        sim.set_option("HIPSIM_LATE_LDS", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+
+
+@pytest.mark.parametrize("which,slack", [("HIPSIM_LGKM_SLACK", 1), ("HIPSIM_VMCNT_SLACK", 1)])
+def test_a_counted_wait_loosened_by_one_fails(sim, port_oracle, which, slack):
+    """The point of the late-landing models: with every counted wait of one kind one operation too loose, the same chain
+    must NOT reproduce the oracle (NaNs from unlanded LDS reads / stale ring slots from unlanded copies)."""
+    sim.set_option("HIPSIM_LATE_LDS", 1)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    sim.set_option(which, slack)
+    try:
+        bad = 0
+        for shape in [(1, 13, 3, 36), (1, 26, 3, 36), (2, 13, 5, 68)]:
+            try:
+                err = _planar_chain(sim, port_oracle, shape, 1)
+                bad += not (max(err.values()) < 5e-5)
+            except AssertionError:
+                bad += 1
+        assert bad > 0, f"{which}={slack} went unnoticed"
+    finally:
+        sim.set_option(which, 0)
+        sim.set_option("HIPSIM_LATE_LDS", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+
+
 # ---- thread scheduling order of the emulator ----------------------------------------------------------------------------
 # Between two barriers the emulator runs the threads of a block one after the other; a hand-off through LDS that lacks a
 # barrier (or a wave barrier where a workgroup barrier is needed) is then decided by the order.  Everything below also
