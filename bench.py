@@ -124,16 +124,15 @@ def stage_timings(inp, iters=5, only=None):
     tp = torch.empty(B * ((DL + 1) // 2) * HL * WL * 2, device=xl.device)
     gtp = torch.empty_like(tp)
     p = lambda t: t.data_ptr()      # noqa: E731
-    npix = N * C * H * W
     names = ["down", "up", "right", "left"]
     gp = [p(g) for g in gs]
     calls = []
     for d in range(4):
-        calls.append((f"sga_scan_fwd_{names[d]}", lambda d=d: lib.call("ganet_sga_scan_forward", p(x), gp[d], p(A[d]), N, C, D, H, W, d, st)))
+        calls.append((f"sga_scan_fwd_{names[d]}", lambda d=d: lib.call("ganet_sga_scan_forward_ws", p(x), gp[d], p(A), N, C, D, H, W, d, st)))
     calls.append(("sga_merge_argmax", lambda: lib.call("ganet_sga_merge", p(A), p(out), p(mask), p(kp), N, C, D, H, W, st)))
     for d in range(4):
-        calls.append((f"sga_bwd_scan_{names[d]}", lambda d=d: lib.call("ganet_sga_backward_scan", gp[d], p(mask), p(kp) + 2 * d * npix,
-                                                                      p(go), p(G[d]), N, C, D, H, W, d, st)))
+        calls.append((f"sga_bwd_scan_{names[d]}", lambda d=d: lib.call("ganet_sga_backward_scan_ws", gp[d], p(mask), p(kp),
+                                                                      p(go), p(G), N, C, D, H, W, d, st)))
     calls.append(("sga_bwd_point", lambda: lib.call("ganet_sga_backward_point", p(x), *gp, p(A), p(G), p(gx), *[p(t) for t in gw],
                                                     N, C, D, H, W, st)))
     calls += [

@@ -21,12 +21,16 @@ _PROTOS = {
     "ganet_abi_version": [],
     "ganet_is_simulator": [],
     "ganet_set_option": [ctypes.c_char_p, _I],
+    "ganet_get_option": [ctypes.c_char_p],
     "ganet_sga_scan_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ganet_sga_forward": [_P] * 9 + [_I] * 5 + [_P],
     "ganet_sga_forward_infer": [_P] * 9 + [_I] * 5 + [_P],
     "ganet_sga_forward_infer_scratch": [_P] * 6 + [_I] * 5,
     "ganet_sga_backward_scan": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_sga_merge": [_P] * 4 + [_I] * 5 + [_P],
+    "ganet_sga_scan_forward_ws": [_P] * 3 + [_I] * 6 + [_P],
+    "ganet_sga_backward_scan_ws": [_P] * 5 + [_I] * 6 + [_P],
+    "ganet_sga_workspace_layout": [_I] * 5,
     "ganet_sga_backward_point": [_P] * 12 + [_I] * 5 + [_P],
     "ganet_sga_backward_dir": [_P] * 9 + [_I] * 7 + [_P],
     "ganet_sga_backward": [_P] * 15 + [_I] * 5 + [_P],
@@ -113,6 +117,9 @@ class CApi:
 
     def set_option(self, name, value):
         self.call("ganet_set_option", name.encode(), int(value))
+
+    def get_option(self, name):
+        return self.query("ganet_get_option", name.encode())
 
 
 _LIB = None

@@ -58,7 +58,12 @@ int check_launch(const char *what)
 // One default path per operator (measured on MI355X, profiles/) plus its general fallback; the knobs exist so that tests can
 // reach the fallbacks and the forced modes.  Fields are atomics: ganet_set_option() may race with launches on other threads
 // (each launcher reads a field once).
+#ifndef GA_SGA_TILED_DEFAULT
+#define GA_SGA_TILED_DEFAULT 0
+#endif
 struct Options {
+  std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA: private tiled layout of the vertical directions' volumes between ganet_sga_forward and
+                                    // ganet_sga_backward: bit 0 the directional volumes A_down / A_up, bit 1 the adjoint volumes G_down / G_up
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
@@ -77,6 +82,7 @@ void load_env_options()
     if (v && *v) dst = atoi(v);
   };
   geti("GANET_LGA_WAVE", g_opt.lga_wave);
+  geti("GANET_SGA_TILED", g_opt.sga_tiled);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
@@ -229,10 +235,10 @@ bool colblock_ok(int D, int W, int dir, size_t smem)
 }
 
 int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
-            int out_mode = 0)
+            int out_mode = 0, int tiled = 0)
 {
   ColGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = out_mode;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = out_mode; geo.tiled = tiled;
   const int dpl = row_dpl(D);
   const bool full = dpl > 0 && D % dpl == 0;
   const size_t smem = col_smem_fwd(D);
@@ -269,7 +275,7 @@ bool col_wide_ok(int D, int W, int dir, size_t smem, int S)
 int col_fwd_wide(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st)
 {
   ColGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0; geo.tiled = 0;
   const int dpl = col_wide_dpl(D);
   const bool full = D % dpl == 0;
   const size_t smem = col_smem_fwd(D);
@@ -292,7 +298,7 @@ int col_bwdg_wide(const float *g, const uint8_t *mask, const uint16_t *kp, const
                   int S, int D, int H, int W, int dir, hipStream_t st)
 {
   ColGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0; geo.tiled = 0;
   const int dpl = col_wide_dpl(D);
   const size_t smem = col_smem_bwdg(D);
   const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(1024);
@@ -312,10 +318,10 @@ int col_bwdg_wide(const float *g, const uint8_t *mask, const uint16_t *kp, const
 }
 
 int col_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
-             int S, int D, int H, int W, int dir, hipStream_t st)
+             int S, int D, int H, int W, int dir, hipStream_t st, int tiled = 0)
 {
   ColGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = 0; geo.tiled = tiled;
   const int dpl = row_dpl(D);
   const size_t smem = col_smem_bwdg(D);
   const dim3 grid((W + COL_NC - 1) / COL_NC, S), block(256);
@@ -367,9 +373,27 @@ bool few_lines(int N, int C, int D, int H, int W, int dir)
   return D >= 96 && lines * 16 < (i64)4 * device_cus() * 64 * 2;      // fewer 16-lane segments than two waves per SIMD hold
 }
 
-int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
-             hipStream_t st)
+// Which of SgaFunction's private volumes take the tiled layout of sga_col_kernels.h for these dimensions: bit 0 A_down / A_up,
+// bit 1 G_down / G_up -- where the 16-lane column-block kernels run (not the wide ones), W % 16 == 0, H % 4 == 0.  Decided
+// from the dimensions and GANET_SGA_TILED alone, so that ganet_sga_forward and ganet_sga_backward agree (do not change the option
+// between the two).
+int sga_ws_tiled(int N, int C, int D, int H, int W)
 {
+  const int want = opts().sga_tiled & 3;
+  if (!want || W % 16 != 0 || H % 4 != 0 || N * C > 65535 || opts().wide_scan == 2) return 0;
+  int m = 0;
+  if ((want & 1) && !col_wide_ok(D, W, 0, col_smem_fwd(D), N * C) && colblock_ok(D, W, 0, col_smem_fwd(D))) m |= 1;
+  if ((want & 2) && !col_wide_ok(D, W, 0, col_smem_bwdg(D), N * C) && colblock_ok(D, W, 0, col_smem_bwdg(D))) m |= 2;
+  return m;
+}
+
+int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
+             hipStream_t st, int tiled = 0)
+{
+  if (tiled) {      // (sga_ws_tiled: the column-block kernel is the one that runs; only the alignment is left to check)
+    if (!(aligned16(x) && aligned16(g) && aligned16(A))) return fail(GANET_E_UNSUPPORTED, "SGA: tiled workspace needs 16-byte aligned volumes");
+    return col_fwd(x, g, A, N * C, D, H, W, dir, st, 0, 1);
+  }
   if (col_wide_ok(D, W, dir, col_smem_fwd(D), N * C) && aligned16(x) && aligned16(g) && aligned16(A))
     return col_fwd_wide(x, g, A, N * C, D, H, W, dir, st);
   if (few_lines(N, C, D, H, W, dir)) {
@@ -396,8 +420,13 @@ int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int 
 }
 
 int scan_bwdg(const float *g, const uint8_t *mask, const uint16_t *kp, const float *gout, float *G,
-              int N, int C, int D, int H, int W, int dir, hipStream_t st)
+              int N, int C, int D, int H, int W, int dir, hipStream_t st, int tiled = 0)
 {
+  if (tiled) {
+    if (!(aligned16(g) && aligned16(gout) && aligned16(G) && (((uintptr_t)mask & 3) == 0)))
+      return fail(GANET_E_UNSUPPORTED, "SGA: tiled workspace needs 16-byte aligned volumes");
+    return col_bwdg(g, mask, kp, gout, G, N * C, D, H, W, dir, st, 1);
+  }
   if (col_wide_ok(D, W, dir, col_smem_bwdg(D), N * C) && aligned16(g) && aligned16(gout) && aligned16(G) &&
       (((uintptr_t)mask & 3) == 0))
     return col_bwdg_wide(g, mask, kp, gout, G, N * C, D, H, W, dir, st);
@@ -449,7 +478,7 @@ int px_grid(i64 npix)
 
 // per-pixel gradients for `ndir` (1 or 4) directions
 int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, int C, int D, int H, int W,
-              int accumulate, hipStream_t st)
+              int accumulate, hipStream_t st, int tiled = 0)
 {
   const i64 npix = (i64)N * C * H * W;
   const int pb = 256;      // (64 / 128 measured equal)
@@ -457,7 +486,12 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
-  if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+  if (ndir == 4 && !accumulate && tiled) {
+    if (tiled == 3) GA_LAUNCH((sga_bwd_point<4, false, true, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+    else if (tiled == 1) GA_LAUNCH((sga_bwd_point<4, false, true, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+    else GA_LAUNCH((sga_bwd_point<4, false, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+  }
+  else if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (accumulate) GA_LAUNCH((sga_bwd_point<1, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else GA_LAUNCH((sga_bwd_point<1, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
@@ -724,11 +758,27 @@ GA_EXPORT int ganet_is_simulator(void)
 #endif
 }
 
+GA_EXPORT int ganet_get_option(const char *name)
+{
+  opts();
+  if (!name) return fail(GANET_E_INVALID, "ganet_get_option: null name");
+  if (!strcmp(name, "GANET_LGA_WAVE")) return g_opt.lga_wave;
+  if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
+  if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
+  if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
+  if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
+  if (!strcmp(name, "GANET_SGA_WIDE_COL")) return g_opt.wide_col;
+  if (!strcmp(name, "GANET_SGA_ROWWAVE")) return g_opt.rowwave;
+  if (!strcmp(name, "GANET_SGA_COLBLOCK")) return g_opt.colblock;
+  return fail(GANET_E_INVALID, "ganet_get_option: unknown option %s", name);
+}
+
 GA_EXPORT int ganet_set_option(const char *name, int value)
 {
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
   if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value & 3;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -768,6 +818,33 @@ GA_EXPORT int ganet_sga_scan_forward(const float *x, const float *g, float *A, i
   return scan_fwd(x, g, A, N, C, D, H, W, dir, (hipStream_t)stream);
 }
 
+GA_EXPORT int ganet_sga_scan_forward_ws(const float *x, const float *g, float *A_ws, int N, int C, int D, int H, int W, int dir,
+                                         void *stream)
+{
+  if (!x || !g || !A_ws) return fail(GANET_E_INVALID, "ganet_sga_scan_forward_ws: null pointer");
+  if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_scan_forward_ws: dir %d", dir);
+  GA_TRY(check_dims5("ganet_sga_scan_forward_ws", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W;
+  return scan_fwd(x, g, A_ws + dir * n, N, C, D, H, W, dir, (hipStream_t)stream, dir < 2 && (sga_ws_tiled(N, C, D, H, W) & 1));
+}
+
+GA_EXPORT int ganet_sga_backward_scan_ws(const float *g, const uint8_t *mask, const uint16_t *kp, const float *grad_out, float *G_ws,
+                                          int N, int C, int D, int H, int W, int dir, void *stream)
+{
+  if (!g || !mask || !kp || !grad_out || !G_ws) return fail(GANET_E_INVALID, "ganet_sga_backward_scan_ws: null pointer");
+  if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_backward_scan_ws: dir %d", dir);
+  GA_TRY(check_dims5("ganet_sga_backward_scan_ws", N, C, D, H, W));
+  const i64 n = (i64)N * C * D * H * W, npix = (i64)N * C * H * W;
+  return scan_bwdg(g, mask, kp + dir * npix, grad_out, G_ws + dir * n, N, C, D, H, W, dir, (hipStream_t)stream,
+                   dir < 2 && (sga_ws_tiled(N, C, D, H, W) & 2));
+}
+
+GA_EXPORT int ganet_sga_workspace_layout(int N, int C, int D, int H, int W)
+{
+  if (check_dims5("ganet_sga_workspace_layout", N, C, D, H, W) != GANET_OK) return GANET_E_INVALID;
+  return sga_ws_tiled(N, C, D, H, W);
+}
+
 GA_EXPORT int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint16_t *kp, int N, int C, int D, int H, int W,
                                void *stream)
 {
@@ -778,8 +855,16 @@ GA_EXPORT int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint
   const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
   const i64 HWl = (i64)H * W;
-  if (HWl % 4 == 0 && aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) &&
-      (((uintptr_t)kp & 7) == 0) && npix / 4 / 64 + 1 < (1ll << 31)) {
+  const bool al = aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
+  if (sga_ws_tiled(N, C, D, H, W) & 1) {
+    if (!al) return fail(GANET_E_UNSUPPORTED, "ganet_sga_merge: tiled workspace needs 16-byte aligned volumes");
+    const i64 nitems = (i64)N * C * (H / 4) * ((W / 16 + 3) / 4);
+    const i64 grid = nitems < (1ll << 30) ? nitems : (1ll << 30);
+    GA_LAUNCH(sga_merge_px4_t, dim3((unsigned)grid), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n, A_ws + 3 * n, out, mask, kp,
+              D, H, W, npix, nitems);
+    return check_launch("sga merge (tiled vertical volumes)");
+  }
+  if (HWl % 4 == 0 && al && npix / 4 / 64 + 1 < (1ll << 31)) {
     GA_LAUNCH(sga_merge_px4, dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
               A_ws + 3 * n, out, mask, kp, D, HWl, npix);
     return check_launch("sga merge (4 px / lane)");
@@ -801,7 +886,8 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   // (the four scans on four streams were measured twice and dropped: 0.596 vs 0.606 ms)
-  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
+  const int tiled = sga_ws_tiled(N, C, D, H, W);
+  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st, d < 2 && (tiled & 1)));
   return ganet_sga_merge(A_ws, out, mask, kp, N, C, D, H, W, stream);
 }
 
@@ -900,7 +986,7 @@ GA_EXPORT int ganet_sga_backward_point(const float *x, const float *g0, const fl
   for (int d = 0; d < 4; d++) {
     pa.G[d] = G_ws + d * n; pa.A[d] = A_ws + d * n; pa.g[d] = gs[d]; pa.gw[d] = gws[d]; pa.dir[d] = d;
   }
-  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, (hipStream_t)stream);
+  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, (hipStream_t)stream, sga_ws_tiled(N, C, D, H, W));
 }
 
 GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
@@ -918,8 +1004,9 @@ GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   float *gws[4] = {gw0, gw1, gw2, gw3};
+  const int tiled = sga_ws_tiled(N, C, D, H, W);
   for (int d = 0; d < 4; d++)
-    GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st));
+    GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st, d < 2 && (tiled & 2)));
   (void)gws;
   return ganet_sga_backward_point(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, stream);
 }

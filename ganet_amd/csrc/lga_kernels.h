@@ -667,13 +667,27 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
   };
   if (TRANSPOSED) {
     // Two sweeps, so that at most ~75 loads are in flight with the 76 weight registers not yet live in the first: (1) the own
-    // taps, reduced to the three sums as they arrive (an interior pixel needs only the two outer slabs: its centre
-    // coefficient is zero); (2) the weights proper, tap (-dd, -a, -b) of the neighbour at (+a, +b).  In one sweep the ~125
-    // destinations plus the weights exceed the 168 registers of three waves per SIMD (13 - 21 spill operations per lane).
+    // taps, reduced to the three sums (an interior pixel needs only the two outer slabs: its centre coefficient is zero);
+    // (2) the weights proper, tap (-dd, -a, -b) of the neighbour at (+a, +b).  In one sweep the ~125 destinations plus the
+    // weights exceed the 168 registers of three waves per SIMD (13 - 21 spill operations per lane).
+    // One depth slab at a time: its K loads are issued back to back into an array, THEN reduced (written as load-and-add per
+    // tap the sums are one dependent chain and hipcc issues load, s_waitcnt vmcnt(0), add, load, ...: 75 serial round trips in
+    // a border tile, +20 % on the whole data-backward pass, profiles/r7a_*).
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (CHECK || t / K != 1) (void)own_tap(t);
-      if (CHECK && (t + 1) % K == 0) GA_SCHED_FENCE();      // (border tiles: one depth slab of loads in flight at a time)
+    for (int dd = 0; dd < 3; dd++) {
+      if (CHECK || dd != 1) {
+        float ow[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) ow[k] = stream_load<(GA_NT_LOADS & 16) != 0>(fb + (i64)(dd * K + k) * geo.HW + pix32);
+        GA_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const int okm = ok_mask(k / WS - R, k % WS - R);
+          cmid += i2f(f2i(ow[k]) & ~okm);
+          if (dd == 0) sin_m += i2f(f2i(ow[k]) & okm);
+          if (dd == 2) sin_p += i2f(f2i(ow[k]) & okm);
+        }
+      }
     }
     GA_SCHED_FENCE();
   }

@@ -16,7 +16,7 @@
 // Arithmetic (fwd_step / bwdg_step) is shared with sga_kernels.h: bit-exact forward.
 #pragma once
 #ifndef GA_COL_TILED_ABLATE
-#define GA_COL_TILED_ABLATE 0      // development only (timing): bit 0 the column scans write their result tiled, bit 1 the adjoint reads its mask tiled
+#define GA_COL_TILED_ABLATE 0      // development only (timing): bit 1 the column adjoint reads its mask as if it were tiled too
 #endif
 #include "ga_common.h"
 #include "sga_kernels.h"
@@ -27,7 +27,24 @@ struct ColGeom {
   int D, H, W;
   i64 HW;
   int out_mode;     // forward scans: 0  A = tile;  1  A = max(A, tile) (running direction max, inference path)
+  int tiled;        // the RESULT volume has the private tiled layout below (directional / adjoint volumes of ganet_sga_forward / _backward)
 };
+
+// ---- private tiled layout of the vertical directions' volumes ------------------------------------------------------------------
+// What limits the column scans at the benchmark size is the pattern of their result stores: per batch a block writes D x 4 runs
+// of 64 bytes (16 columns of one plane row) with an 832-byte row pitch -- 3.1 - 3.5 TB/s where a linear fill reaches 4.4 - 5.0
+// (profiles/r3c_*, r3d_*).  The four directional volumes A_dir and the four adjoint volumes G_dir are PRIVATE to SgaFunction
+// (they exist between ganet_sga_forward and ganet_sga_backward only), so the two vertical directions keep theirs tiled:
+//     element (s, d, h, w)  ->  ((((s * NCB + w / 16) * NRB + h / 4) * D + d) * 4 + h % 4) * 16 + w % 16,   NCB = W / 16, NRB = H / 4
+// i.e. [slice][column block][row batch][d][4 rows][16 columns]: a block's batch is ONE contiguous burst of D * 256 bytes, a
+// thread's 16-byte piece lands at 16 * tid.  Same size as the API layout (needs W % 16 == 0 and H % 4 == 0; otherwise the
+// volume stays in the API layout).  Readers: sga_merge_px4_t (a wave = 4 column blocks x 4 rows, 256-byte runs) and
+// sga_bwd_point (64-byte runs).  Timing experiment that motivated it: profiles/r7a_ab_sga_stages.txt -- column forward scans
+// 72 -> 61 us, adjoint 98 -> 82 us with tiled result stores.
+GA_DEV i64 col_tiled_off(int s, int ncb, int cb, int H, int D, int d, int row)
+{
+  return ((((i64)s * ncb + cb) * (H >> 2) + (row >> 2)) * D + d) * 64 + (row & 3) * 16;
+}
 
 constexpr int COL_SBV = 4;     // rows (scan positions) per staged batch = one ds_read_b128
 constexpr int COL_NC = 16;     // columns per block

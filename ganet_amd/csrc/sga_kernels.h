@@ -538,7 +538,9 @@ struct PointArgs {
 #ifndef GA_POINT_WAVES
 #define GA_POINT_WAVES 5
 #endif
-template <int NDIR, bool ACC>
+// TA / TG: the forward / adjoint volumes of the two vertical directions (pa.dir < 2) have the private tiled layout
+// (sga_col_kernels.h): plane stride 64 instead of H W, the pixel's offset and that of its previous scan position computed once.
+template <int NDIR, bool ACC, bool TA = false, bool TG = false>
 __global__ void __launch_bounds__(256, GA_POINT_WAVES)
 sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa,
               int D, int H, int W, i64 npix)
@@ -559,6 +561,9 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
     const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
     const i64 vb = s * D * HW + pix;
     const i64 gbo = s * 5 * HW + pix;
+    // tiled volumes: offset of (s, plane 0, h, w); a vertical neighbour is 16 elements away inside a row batch, D * 64 - 48 across
+    i64 tb = 0;
+    if (TA || TG) tb = (((s * (W >> 4) + (w >> 4)) * (H >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
     float w0[NDIR], w2[NDIR], w3[NDIR];
     int poff[NDIR];          // previous position in forward order (0 = none, see hpm)
     unsigned hpm = 0;        // bit q: direction q has a previous position at this pixel
@@ -573,11 +578,16 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
       // down: h-1, up: h+1, right: w-1, left: w+1
       const bool hp = dir == 0 ? h > 0 : dir == 1 ? h + 1 < H : dir == 2 ? w > 0 : w + 1 < W;
       poff[q] = hp ? (dir == 0 ? -W : dir == 1 ? W : dir == 2 ? -1 : 1) : 0;
+      static_assert(!(TA || TG) || NDIR == 4, "tiled volumes: the four-direction launch only (direction q in slot q)");
+      if (TA && q < 2 && hp) {
+        if (dir == 0) poff[q] = (h & 3) ? -16 : -(D * 64) + 48;          // row h - 1
+        else poff[q] = (h & 3) != 3 ? 16 : D * 64 - 48;                  // row h + 1
+      }
       hpm |= hp ? (1u << q) : 0u;
       s0[q] = s1[q] = s2[q] = s3[q] = sg[q] = 0.f;
       mx[q] = -INFINITY;
       a_m[q] = 0.f;
-      a_0[q] = pa.A[q][vb + poff[q]];
+      a_0[q] = pa.A[q][(TA && q < 2 ? tb : vb) + poff[q]];
     }
     constexpr int DU = GA_POINT_DU;
     for (int dc = 0; dc < D; dc += DU) {
@@ -590,12 +600,15 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
         const int d = dc + u;
         const i64 o = vb + (i64)(d < D ? d : D - 1) * HW;
         const i64 on = vb + (i64)(d + 1 < D ? d + 1 : D - 1) * HW;
+        const i64 ot = tb + (i64)(d < D ? d : D - 1) * 64;
+        const i64 otn = tb + (i64)(d + 1 < D ? d + 1 : D - 1) * 64;
         xv[u] = stream_load<(GA_NT_LOADS & 8) != 0>(x + o);
         gxv[u] = ACC ? gradX[o] : 0.f;
 #pragma unroll
         for (int q = 0; q < NDIR; q++) {
-          Gv[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.G[q] + o);
-          Av[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + on + poff[q]);                          // A[pp][d+1] (used only where d + 1 < D)
+          const bool vert = NDIR == 4 && q < 2;      // (the four-direction launch passes direction q in slot q)
+          Gv[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.G[q] + ((TG && vert) ? ot : o));
+          Av[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + ((TA && vert) ? otn : on) + poff[q]);     // A[pp][d+1] (used only where d + 1 < D)
         }
       }
 #pragma unroll
@@ -711,6 +724,92 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
         const i64 o = vb + (i64)d * HW;
         a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o));
         a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o));
+        a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
+        a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
+      }
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u;
+        if (d < D) {
+          float v[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) { v[q][0] = a[u][q].x; v[q][1] = a[u][q].y; v[q][2] = a[u][q].z; v[q][3] = a[u][q].w; }
+          float ov[4];
+          unsigned mk = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float o_ = v[0][j];
+            unsigned mj = 0;
+            if (o_ < v[1][j]) { o_ = v[1][j]; mj = 1; }
+            if (o_ < v[2][j]) { o_ = v[2][j]; mj = 2; }
+            if (o_ < v[3][j]) { o_ = v[3][j]; mj = 3; }
+            ov[j] = o_;
+            mk |= mj << (8 * j);
+          }
+          const i64 o = vb + (i64)d * HW;
+          f4 r;
+          r.x = ov[0]; r.y = ov[1]; r.z = ov[2]; r.w = ov[3];
+          stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<f4 *>(out + o), r);
+          stream_store<(GA_NT_STORES & 128) != 0>(reinterpret_cast<unsigned *>(mask + o), mk);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (d == 0) m[q][j] = v[q][j];
+              else if (m[q][j] < v[q][j]) { m[q][j] = v[q][j]; k[q][j] = d; }
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint2 pk;
+      pk.x = (unsigned)k[q][0] | ((unsigned)k[q][1] << 16);
+      pk.y = (unsigned)k[q][2] | ((unsigned)k[q][3] << 16);
+      *reinterpret_cast<uint2 *>(kp + (i64)q * npix + pidx) = pk;
+    }
+  }
+}
+
+// The same merge with the two VERTICAL directional volumes (A0, A1) in the private tiled layout (sga_col_kernels.h):
+// a wavefront = 4 neighbouring column blocks x 4 rows x 16 columns, lane = (column block, row, 4-column piece), so that its 16
+// lanes of a column block read 256 contiguous bytes of the tiled volumes per plane and the whole wave 4 rows x 256 bytes of the
+// API-layout ones (A2, A3, out, mask).  Work item = (slice, row batch, group of 4 column blocks); needs W % 16 == 0, H % 4 == 0.
+static __global__ void __launch_bounds__(64)
+sga_merge_px4_t(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
+                const float *__restrict__ A3, float *__restrict__ out, uint8_t *__restrict__ mask,
+                uint16_t *__restrict__ kp, int D, int H, int W, i64 npix, i64 nitems)
+{
+  constexpr int DU = GA_MERGE_DU;
+  const i64 HW = (i64)H * W;
+  const int ncb = W >> 4, nrb = H >> 2, ncb4 = (ncb + 3) >> 2;
+  const int lane = threadIdx.x;
+  const int cbl = lane >> 4, rj = (lane >> 2) & 3, piece = lane & 3;
+  for (i64 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int cb4 = (int)(item % ncb4);
+    const i64 t_ = item / ncb4;
+    const int rb = (int)(t_ % nrb);
+    const i64 s = t_ / nrb;
+    const int cb = 4 * cb4 + cbl;
+    if (cb >= ncb) continue;                       // (per-lane: the last group of a row may hold fewer than 4 column blocks)
+    const int h = 4 * rb + rj, w = 16 * cb + 4 * piece;
+    const i64 pix = (i64)h * W + w, pidx = s * HW + pix;
+    const i64 vb = s * D * HW + pix;                                                    // API layout, plane 0
+    const i64 tb = (((s * ncb + cb) * nrb + rb) * D) * 64 + rj * 16 + 4 * piece;        // tiled layout, plane 0
+    float m[4][4];
+    int k[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { m[q][j] = 0.f; k[q][j] = 0; }
+    for (int dc = 0; dc < D; dc += DU) {
+      f4 a[DU][4];
+#pragma unroll
+      for (int u = 0; u < DU; u++) {
+        const int d = dc + u < D ? dc + u : D - 1;
+        const i64 o = vb + (i64)d * HW, ot = tb + (i64)d * 64;
+        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + ot));
+        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + ot));
         a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
         a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
       }

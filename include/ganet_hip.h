@@ -60,8 +60,20 @@ int ganet_sga_forward(const float *x, const float *g0, const float *g1, const fl
                       const float *g3, float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
                       int N, int C, int D, int H, int W, void *stream);
 
+/* The steps of ganet_sga_forward / ganet_sga_backward as they run inside those calls: direction `dir`'s scan into its place in
+ * the op's PRIVATE workspace (A_ws / G_ws: [4][N*C*D*H*W] floats; kp: the whole [4][N*C*H*W] array).  The workspace is not in
+ * the API layout in general: ganet_sga_workspace_layout() says which of its volumes are tiled for these dimensions (bit 0:
+ * A_down / A_up, bit 1: G_down / G_up; element (s, d, h, w) at ((((s * W/16 + w/16) * H/4 + h/4) * D + d) * 4 + h%4) * 16 + w%16).
+ * ganet_sga_scan_forward / ganet_sga_backward_scan (above) always write the API layout.
+ * Replaces: the same reference code as ganet_sga_scan_forward / ganet_sga_backward_scan. */
+int ganet_sga_scan_forward_ws(const float *x, const float *g, float *A_ws,
+                              int N, int C, int D, int H, int W, int dir, void *stream);
+int ganet_sga_backward_scan_ws(const float *g, const uint8_t *mask, const uint16_t *kp, const float *grad_out, float *G_ws,
+                               int N, int C, int D, int H, int W, int dir, void *stream);
+int ganet_sga_workspace_layout(int N, int C, int D, int H, int W);
+
 /* The last step of ganet_sga_forward on its own: out / mask / kp from the four directional volumes in A_ws (same buffers, same
- * layouts).  ganet_sga_forward == 4 x ganet_sga_scan_forward + this; exported so that a caller (bench.py) can time it in place.
+ * layouts).  ganet_sga_forward == 4 x ganet_sga_scan_forward_ws + this; exported so that a caller (bench.py) can time it in place.  A_ws as ganet_sga_scan_forward_ws leaves it.
  * Replaces: the three `Max` launches (GANet_kernel.cu:23-36, 964-994) and the four MaxDepth launches of the backward (:50-64). */
 int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint16_t *kp,
                     int N, int C, int D, int H, int W, void *stream);
@@ -109,7 +121,7 @@ int ganet_sga_backward(const float *x, const float *g0, const float *g1, const f
                        float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
 
 /* The last step of ganet_sga_backward on its own: every gradient from the four adjoint volumes in G_ws (written by
- * ganet_sga_backward_scan) and the forward volumes in A_ws.  ganet_sga_backward == 4 x ganet_sga_backward_scan + this.
+ * ganet_sga_backward_scan_ws) and the forward volumes in A_ws.  ganet_sga_backward == 4 x ganet_sga_backward_scan_ws + this.
  * Replaces: the bottom_diff part of sga_*_data_backward (:182-207 & mirrors) + sga_*_weight_backward (:210-281 & mirrors). */
 int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
                              const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1,
@@ -276,6 +288,8 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  * fwd+bwd); GANET_SGA_SAVE=recompute selects the reference's memory profile.  GANET_TRACE_DISPATCH=1 prints which LGA kernel
  * a call took.  Unknown names -> GANET_E_INVALID. */
 int ganet_set_option(const char *name, int value);
+/* current value of a library option (>= 0), GANET_E_INVALID for an unknown name */
+int ganet_get_option(const char *name);
 
 #ifdef __cplusplus
 }

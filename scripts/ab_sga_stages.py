@@ -8,7 +8,11 @@ import torch, bench
 from ganet_amd import _native
 for rep in range(2):
     for name in sys.argv[1:]:
-        _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", name), strict=False)
+        libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value
+        _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
+        for kv in filter(None, optstr.split(",")):
+            k, v = kv.split("=")
+            _native._LIB.set_option(k, int(v))
         inp = bench.make_inputs(torch.device("cuda:0"))
         st = bench.stage_timings(inp, iters=10, only="sga")
         print(name, {k: round(v, 4) for k, v in st.items() if k.startswith("sga")}, flush=True)

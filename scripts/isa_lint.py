@@ -10,8 +10,8 @@ from ganet_amd import build
 want = sys.argv[1:]
 for src, extra in build.SOURCES.items():
     with tempfile.NamedTemporaryFile(suffix=".s") as tf:
-        subprocess.run(["hipcc"] + build.HIPCC_FLAGS + extra + ["-I", build.CSRC, "-S", "--cuda-device-only",
-                        os.path.join(build.CSRC, src), "-o", tf.name], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run(["hipcc"] + build.HIPCC_FLAGS + extra + ["-I", os.environ.get("ISA_CSRC", build.CSRC), "-S", "--cuda-device-only",
+                        os.path.join(os.environ.get("ISA_CSRC", build.CSRC), src), "-o", tf.name], check=True, stderr=subprocess.DEVNULL)
         txt = open(tf.name).read().split("\n")
     cur, res = None, {}
     for i, l in enumerate(txt):

@@ -89,6 +89,14 @@ def check_sga_scan(api, dev, oracle, x, g, direction):
     assert np.array_equal(got, want), f"dir {direction}: {int((got != want).sum())} of {got.size} differ, max {np.abs(got - want).max()}"
 
 
+def untile_ws(t):
+    """[N,C,D,H,W] array holding a vertical direction's volume in SgaFunction's private tiled layout
+    ([slice][W/16][H/4][D][4][16], include/ganet_hip.h: ganet_sga_workspace_layout) -> the API layout."""
+    N, C, D, H, W = t.shape
+    v = t.reshape(N * C, W // 16, H // 4, D, 4, 16)          # (s, cb, rb, d, rj, cw)
+    return np.ascontiguousarray(v.transpose(0, 3, 2, 4, 1, 5)).reshape(N, C, D, H, W)
+
+
 def run_sga_forward(api, dev, x, gs):
     N, C, D, H, W = x.shape
     dx = dev.to(x)
@@ -108,7 +116,13 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
     per_dir=False skips the cross-check of the per-direction entry point (large volumes)."""
     N, C, D, H, W = x.shape
     dx, dg, A, out, mask, kp = run_sga_forward(api, dev, x, gs)
+    layout = api.query("ganet_sga_workspace_layout", N, C, D, H, W)      # bit 0: A_down / A_up tiled, bit 1: G_down / G_up
     hA = dev.host(A)
+    if layout & 1:
+        hA = hA.copy()
+        for d in range(2):
+            hA[d] = untile_ws(hA[d])
+        per_dir = False          # (ganet_sga_backward_dir takes an API-layout volume)
     for d in range(4):
         if f"A{d}" in want:
             assert np.array_equal(hA[d], want[f"A{d}"]), f"A{d}"
@@ -134,13 +148,13 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
         dev.sync()
         assert np.abs(dev.host(gw1) - dev.host(gw[d])).max() <= 1e-6
     assert np.abs(dev.host(gx1) - dev.host(gx)).max() <= 1e-5
-    if per_dir:
+    if True:
         # ABI 8: the composite entries are their steps -- 4 x scan + ganet_sga_merge, 4 x adjoint scan +
         # ganet_sga_backward_point -- bit for bit (bench.py times the steps in place)
         A2, out2 = dev.empty((4,) + x.shape), dev.empty(x.shape)
         mask2, kp2 = dev.empty(x.shape, np.uint8), dev.empty((4, N, C, H, W), np.uint16)
         for d in range(4):
-            api.call("ganet_sga_scan_forward", dev.ptr(dx), dev.ptr(dg[d]), dev.ptr(A2) + 4 * d * x.size, N, C, D, H, W, d, dev.stream)
+            api.call("ganet_sga_scan_forward_ws", dev.ptr(dx), dev.ptr(dg[d]), dev.ptr(A2), N, C, D, H, W, d, dev.stream)
         api.call("ganet_sga_merge", dev.ptr(A2), dev.ptr(out2), dev.ptr(mask2), dev.ptr(kp2), N, C, D, H, W, dev.stream)
         dev.sync()
         assert np.array_equal(dev.host(out2), dev.host(out)) and np.array_equal(dev.host(mask2), dev.host(mask))
@@ -148,8 +162,8 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
         G2, gx2 = dev.empty((4,) + x.shape), dev.empty(x.shape)
         gw2 = [dev.empty(gs[0].shape) for _ in range(4)]
         for d in range(4):
-            api.call("ganet_sga_backward_scan", dev.ptr(dg[d]), dev.ptr(mask), dev.ptr(kp) + 2 * d * (N * C * H * W), dev.ptr(dgo),
-                     dev.ptr(G2) + 4 * d * x.size, N, C, D, H, W, d, dev.stream)
+            api.call("ganet_sga_backward_scan_ws", dev.ptr(dg[d]), dev.ptr(mask), dev.ptr(kp), dev.ptr(dgo),
+                     dev.ptr(G2), N, C, D, H, W, d, dev.stream)
         api.call("ganet_sga_backward_point", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(G2), dev.ptr(gx2),
                  *[dev.ptr(g) for g in gw2], N, C, D, H, W, dev.stream)
         dev.sync()

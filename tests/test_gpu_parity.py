@@ -167,6 +167,24 @@ def test_full_size_cfg2_against_oracle(api, dev, port_oracle):
     print("cfg2 LGA2 max-abs errors:", err)
 
 
+@pytest.mark.parametrize("tiled", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(1, 32, 65, 80, 208), (1, 4, 33, 8, 48), (2, 3, 48, 12, 80), (1, 2, 9, 4, 16)])
+def test_sga_tiled_private_workspace(api, dev, port_oracle, shape, tiled):
+    """GANET_SGA_TILED (sga_col_kernels.h): the vertical directions' volumes of SgaFunction's private workspace tiled
+    [slice][W/16][H/4][D][4][16] -- written by the column scans, read by sga_merge_px4_t / sga_bwd_point<.., TA, TG>.  Outputs,
+    mask and arg-max bit-exact, gradients within 1e-4, at the full cfg2 size and at sizes with one / three / five column blocks."""
+    was = api.get_option("GANET_SGA_TILED")
+    api.set_option("GANET_SGA_TILED", tiled)
+    try:
+        N, C, D, H, W = shape
+        assert api.query("ganet_sga_workspace_layout", N, C, D, H, W) == tiled
+        x, gs, go = pc.sga_inputs(shape, seed=7 + tiled)
+        err = pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+        assert max(err.values()) <= pc.TOL, err
+    finally:
+        api.set_option("GANET_SGA_TILED", was)
+
+
 def test_full_size_properties(api, dev):
     """Size-independent properties at the full cfg2 shapes (no oracle involved):
     SGA is positively homogeneous -- scaling x by 2 scales every volume by exactly 2 and leaves
