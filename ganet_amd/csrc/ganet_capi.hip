@@ -856,17 +856,14 @@ GA_EXPORT int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint
   hipStream_t st = (hipStream_t)stream;
   const i64 HWl = (i64)H * W;
   const bool al = aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
-  if (sga_ws_tiled(N, C, D, H, W) & 1) {
-    if (!al) return fail(GANET_E_UNSUPPORTED, "ganet_sga_merge: tiled workspace needs 16-byte aligned volumes");
-    const i64 nitems = (i64)N * C * (H / 4) * ((W / 16 + 3) / 4);
-    const i64 grid = nitems < (1ll << 30) ? nitems : (1ll << 30);
-    GA_LAUNCH(sga_merge_px4_t, dim3((unsigned)grid), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n, A_ws + 3 * n, out, mask, kp,
-              D, H, W, npix, nitems);
-    return check_launch("sga merge (tiled vertical volumes)");
-  }
+  const bool ta = (sga_ws_tiled(N, C, D, H, W) & 1) != 0;
+  if (ta && !(al && npix / 4 / 64 + 1 < (1ll << 31)))
+    return fail(GANET_E_UNSUPPORTED, "ganet_sga_merge: tiled workspace needs 16-byte aligned volumes");
   if (HWl % 4 == 0 && al && npix / 4 / 64 + 1 < (1ll << 31)) {
-    GA_LAUNCH(sga_merge_px4, dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
-              A_ws + 3 * n, out, mask, kp, D, HWl, npix);
+    if (ta) GA_LAUNCH((sga_merge_px4<true>), dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
+                      A_ws + 3 * n, out, mask, kp, D, HWl, npix, W);
+    else GA_LAUNCH((sga_merge_px4<false>), dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
+                   A_ws + 3 * n, out, mask, kp, D, HWl, npix, W);
     return check_launch("sga merge (4 px / lane)");
   }
   GA_LAUNCH((sga_merge_px<uint8_t>), dim3(px_grid(npix)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,

@@ -38,8 +38,8 @@ struct ColGeom {
 //     element (s, d, h, w)  ->  ((((s * NCB + w / 16) * NRB + h / 4) * D + d) * 4 + h % 4) * 16 + w % 16,   NCB = W / 16, NRB = H / 4
 // i.e. [slice][column block][row batch][d][4 rows][16 columns]: a block's batch is ONE contiguous burst of D * 256 bytes, a
 // thread's 16-byte piece lands at 16 * tid.  Same size as the API layout (needs W % 16 == 0 and H % 4 == 0; otherwise the
-// volume stays in the API layout).  Readers: sga_merge_px4_t (a wave = 4 column blocks x 4 rows, 256-byte runs) and
-// sga_bwd_point (64-byte runs).  Timing experiment that motivated it: profiles/r7a_ab_sga_stages.txt -- column forward scans
+// volume stays in the API layout).  Readers: sga_merge_px4<true> and sga_bwd_point<.., TA, TG> (64-byte runs per plane:
+// reads tolerate them, stores do not).  Timing experiment that motivated it: profiles/r7a_ab_sga_stages.txt -- column forward scans
 // 72 -> 61 us, adjoint 98 -> 82 us with tiled result stores.
 GA_DEV i64 col_tiled_off(int s, int ncb, int cb, int H, int D, int d, int row)
 {

@@ -698,10 +698,15 @@ sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const f
 #ifndef GA_MERGE_DU
 #define GA_MERGE_DU 2      // planes of loads in flight per lane: 1 was best with plain loads (round 1); with the non-temporal loads 2 is (whole step -0.9 ... -1.2 % on two boxes, profiles/r4a_*)
 #endif
-static __global__ void __launch_bounds__(64)
+// TA: the two VERTICAL directional volumes (A0, A1) have the private tiled layout of sga_col_kernels.h (W = the image width,
+// W % 16 == 0, H % 4 == 0): the lane's four pixels are 16 contiguous bytes there as well, 64-byte runs per (column block, row)
+// and plane instead of the wave's 1 KB -- which these reads tolerate (measured, profiles/r7b_*), unlike the result stores: a
+// first version gave the wave a tile-congruent pixel set (4 column blocks x 4 rows) and lost 53 us on its API-layout streams.
+template <bool TA>
+__global__ void __launch_bounds__(64)
 sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
               const float *__restrict__ A3, float *__restrict__ out, uint8_t *__restrict__ mask,
-              uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
+              uint16_t *__restrict__ kp, int D, i64 HW, i64 npix, int W)
 {
   constexpr int DU = GA_MERGE_DU;
   const i64 nq = npix >> 2;
@@ -710,6 +715,11 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
     const i64 pidx = qidx << 2;
     const i64 s = pidx / HW, pix = pidx - s * HW;
     const i64 vb = s * D * HW + pix;
+    i64 tb = 0;            // tiled volumes: offset of the quad at plane 0, plane stride 64
+    if (TA) {
+      const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
+      tb = (((s * (W >> 4) + (w >> 4)) * (int)((HW / W) >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
+    }
     float m[4][4];
     int k[4][4];
 #pragma unroll
@@ -722,94 +732,9 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
       for (int u = 0; u < DU; u++) {
         const int d = dc + u < D ? dc + u : D - 1;
         const i64 o = vb + (i64)d * HW;
-        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o));
-        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o));
-        a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
-        a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
-      }
-#pragma unroll
-      for (int u = 0; u < DU; u++) {
-        const int d = dc + u;
-        if (d < D) {
-          float v[4][4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) { v[q][0] = a[u][q].x; v[q][1] = a[u][q].y; v[q][2] = a[u][q].z; v[q][3] = a[u][q].w; }
-          float ov[4];
-          unsigned mk = 0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            float o_ = v[0][j];
-            unsigned mj = 0;
-            if (o_ < v[1][j]) { o_ = v[1][j]; mj = 1; }
-            if (o_ < v[2][j]) { o_ = v[2][j]; mj = 2; }
-            if (o_ < v[3][j]) { o_ = v[3][j]; mj = 3; }
-            ov[j] = o_;
-            mk |= mj << (8 * j);
-          }
-          const i64 o = vb + (i64)d * HW;
-          f4 r;
-          r.x = ov[0]; r.y = ov[1]; r.z = ov[2]; r.w = ov[3];
-          stream_store<(GA_NT_STORES & 4) != 0>(reinterpret_cast<f4 *>(out + o), r);
-          stream_store<(GA_NT_STORES & 128) != 0>(reinterpret_cast<unsigned *>(mask + o), mk);
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (d == 0) m[q][j] = v[q][j];
-              else if (m[q][j] < v[q][j]) { m[q][j] = v[q][j]; k[q][j] = d; }
-            }
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      uint2 pk;
-      pk.x = (unsigned)k[q][0] | ((unsigned)k[q][1] << 16);
-      pk.y = (unsigned)k[q][2] | ((unsigned)k[q][3] << 16);
-      *reinterpret_cast<uint2 *>(kp + (i64)q * npix + pidx) = pk;
-    }
-  }
-}
-
-// The same merge with the two VERTICAL directional volumes (A0, A1) in the private tiled layout (sga_col_kernels.h):
-// a wavefront = 4 neighbouring column blocks x 4 rows x 16 columns, lane = (column block, row, 4-column piece), so that its 16
-// lanes of a column block read 256 contiguous bytes of the tiled volumes per plane and the whole wave 4 rows x 256 bytes of the
-// API-layout ones (A2, A3, out, mask).  Work item = (slice, row batch, group of 4 column blocks); needs W % 16 == 0, H % 4 == 0.
-static __global__ void __launch_bounds__(64)
-sga_merge_px4_t(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
-                const float *__restrict__ A3, float *__restrict__ out, uint8_t *__restrict__ mask,
-                uint16_t *__restrict__ kp, int D, int H, int W, i64 npix, i64 nitems)
-{
-  constexpr int DU = GA_MERGE_DU;
-  const i64 HW = (i64)H * W;
-  const int ncb = W >> 4, nrb = H >> 2, ncb4 = (ncb + 3) >> 2;
-  const int lane = threadIdx.x;
-  const int cbl = lane >> 4, rj = (lane >> 2) & 3, piece = lane & 3;
-  for (i64 item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int cb4 = (int)(item % ncb4);
-    const i64 t_ = item / ncb4;
-    const int rb = (int)(t_ % nrb);
-    const i64 s = t_ / nrb;
-    const int cb = 4 * cb4 + cbl;
-    if (cb >= ncb) continue;                       // (per-lane: the last group of a row may hold fewer than 4 column blocks)
-    const int h = 4 * rb + rj, w = 16 * cb + 4 * piece;
-    const i64 pix = (i64)h * W + w, pidx = s * HW + pix;
-    const i64 vb = s * D * HW + pix;                                                    // API layout, plane 0
-    const i64 tb = (((s * ncb + cb) * nrb + rb) * D) * 64 + rj * 16 + 4 * piece;        // tiled layout, plane 0
-    float m[4][4];
-    int k[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) { m[q][j] = 0.f; k[q][j] = 0; }
-    for (int dc = 0; dc < D; dc += DU) {
-      f4 a[DU][4];
-#pragma unroll
-      for (int u = 0; u < DU; u++) {
-        const int d = dc + u < D ? dc + u : D - 1;
-        const i64 o = vb + (i64)d * HW, ot = tb + (i64)d * 64;
-        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + ot));
-        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + ot));
+        const i64 o01 = TA ? tb + (i64)d * 64 : o;
+        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o01));
+        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o01));
         a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
         a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
       }

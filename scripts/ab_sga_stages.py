@@ -10,7 +10,13 @@ for rep in range(2):
     for name in sys.argv[1:]:
         libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value
         _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
-        for kv in filter(None, optstr.split(",")):
+        for k_ in ("GANET_SGA_TILED",):                   # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+            try: _native._LIB.set_option(k_, 0)
+            except Exception: pass
+        for k_ in ("GANET_SGA_TILED",):                   # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+        try: _native._LIB.set_option(k_, 0)
+        except Exception: pass
+    for kv in filter(None, optstr.split(",")):
             k, v = kv.split("=")
             _native._LIB.set_option(k, int(v))
         inp = bench.make_inputs(torch.device("cuda:0"))
