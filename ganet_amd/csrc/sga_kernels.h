@@ -733,8 +733,11 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
         const int d = dc + u < D ? dc + u : D - 1;
         const i64 o = vb + (i64)d * HW;
         const i64 o01 = TA ? tb + (i64)d * 64 : o;
-        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o01));
-        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o01));
+        // (tiled volumes: plain loads -- a 128-byte line there holds the same 16 columns of TWO rows, i.e. two different
+        // waves' 64-byte runs; a non-temporal load lets the line go before the second one arrives and it is fetched twice:
+        // the whole step +2.9 % with them, profiles/r7c_ab_step.txt)
+        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0 && !TA>(reinterpret_cast<const f4 *>(A0 + o01));
+        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0 && !TA>(reinterpret_cast<const f4 *>(A1 + o01));
         a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
         a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
       }

@@ -7,12 +7,14 @@ for rep in range(2):
     for name in sys.argv[1:]:
         libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value
         _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
-        for k_ in ("GANET_SGA_TILED",):                   # RESET_OPTS: options are process-wide in the library: back to off unless asked for
-            try: _native._LIB.set_option(k_, 0)
-            except Exception: pass
-        for k_ in ("GANET_SGA_TILED",):                   # RESET_OPTS: options are process-wide in the library: back to off unless asked for
-        try: _native._LIB.set_option(k_, 0)
-        except Exception: pass
+        try:
+            _native._LIB.set_option("GANET_SGA_TILED", 0)          # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+        except Exception:
+            pass
+        try:
+        _native._LIB.set_option("GANET_SGA_TILED", 0)              # RESET_OPTS
+    except Exception:
+        pass
     for kv in filter(None, optstr.split(",")):
             k, v = kv.split("=")
             _native._LIB.set_option(k, int(v))

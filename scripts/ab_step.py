@@ -17,9 +17,10 @@ pool = torch.cuda.graph_pool_handle()
 for idx, name in enumerate(sys.argv[1:]):
     libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value: ganet_set_option before the capture
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
-    for k_ in ("GANET_SGA_TILED",):                   # RESET_OPTS: options are process-wide in the library: back to off unless asked for
-        try: _native._LIB.set_option(k_, 0)
-        except Exception: pass
+    try:
+        _native._LIB.set_option("GANET_SGA_TILED", 0)              # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+    except Exception:
+        pass
     for kv in filter(None, optstr.split(",")):
         k, v = kv.split("=")
         if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE"):      # read by the Python layer from the environment at every call
