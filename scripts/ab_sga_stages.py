@@ -1,6 +1,6 @@
-"""Same-box SGA stage timings (bench.stage_timings: the four scans of a pass in sequence, merge / per-pixel kernel) for several
-builds of the library: python scripts/ab_sga_stages.py libA.so libB.so ...  (timing-only ablation builds included: their
-results are not checked here)."""
+"""Same-box SGA stage timings (bench.stage_timings: every SGA kernel of the step in sequence) for several builds / option
+settings of the library: python scripts/ab_sga_stages.py libA.so libB.so@GANET_SGA_TILED=2 ...  (timing-only ablation builds
+included: their results are not checked here)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,14 +11,10 @@ for rep in range(2):
         libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value
         _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
         try:
-            _native._LIB.set_option("GANET_SGA_TILED", 0)          # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+            _native._LIB.set_option("GANET_SGA_TILED", 0)  # options are process-wide in the library: back to off unless asked for
         except Exception:
             pass
-        try:
-        _native._LIB.set_option("GANET_SGA_TILED", 0)              # RESET_OPTS
-    except Exception:
-        pass
-    for kv in filter(None, optstr.split(",")):
+        for kv in filter(None, optstr.split(",")):
             k, v = kv.split("=")
             _native._LIB.set_option(k, int(v))
         inp = bench.make_inputs(torch.device("cuda:0"))
