@@ -59,11 +59,11 @@ int check_launch(const char *what)
 // reach the fallbacks and the forced modes.  Fields are atomics: ganet_set_option() may race with launches on other threads
 // (each launcher reads a field once).
 #ifndef GA_SGA_TILED_DEFAULT
-#define GA_SGA_TILED_DEFAULT 0
+#define GA_SGA_TILED_DEFAULT 1
 #endif
 struct Options {
-  std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA: private tiled layout of the vertical directions' volumes between ganet_sga_forward and
-                                    // ganet_sga_backward: bit 0 the directional volumes A_down / A_up, bit 1 the adjoint volumes G_down / G_up
+  std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
+                                    // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
@@ -235,10 +235,10 @@ bool colblock_ok(int D, int W, int dir, size_t smem)
 }
 
 int col_fwd(const float *x, const float *g, float *A, int S, int D, int H, int W, int dir, hipStream_t st,
-            int out_mode = 0, int tiled = 0)
+            int out_mode = 0)
 {
   ColGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = out_mode; geo.tiled = tiled;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W; geo.out_mode = out_mode; geo.tiled = 0;
   const int dpl = row_dpl(D);
   const bool full = dpl > 0 && D % dpl == 0;
   const size_t smem = col_smem_fwd(D);
@@ -373,27 +373,17 @@ bool few_lines(int N, int C, int D, int H, int W, int dir)
   return D >= 96 && lines * 16 < (i64)4 * device_cus() * 64 * 2;      // fewer 16-lane segments than two waves per SIMD hold
 }
 
-// Which of SgaFunction's private volumes take the tiled layout of sga_col_kernels.h for these dimensions: bit 0 A_down / A_up,
-// bit 1 G_down / G_up -- where the 16-lane column-block kernels run (not the wide ones), W % 16 == 0, H % 4 == 0.  Decided
-// from the dimensions and GANET_SGA_TILED alone, so that ganet_sga_forward and ganet_sga_backward agree (do not change the option
-// between the two).
+// 1 if ganet_sga_backward keeps G_down / G_up in the tiled layout of sga_col_kernels.h for these dimensions: where the 16-lane
+// column-block adjoint kernel runs (not the wide one), W % 16 == 0, H % 4 == 0.  Decided from the dimensions and GANET_SGA_TILED.
 int sga_ws_tiled(int N, int C, int D, int H, int W)
 {
-  const int want = opts().sga_tiled & 3;
-  if (!want || W % 16 != 0 || H % 4 != 0 || N * C > 65535 || opts().wide_scan == 2) return 0;
-  int m = 0;
-  if ((want & 1) && !col_wide_ok(D, W, 0, col_smem_fwd(D), N * C) && colblock_ok(D, W, 0, col_smem_fwd(D))) m |= 1;
-  if ((want & 2) && !col_wide_ok(D, W, 0, col_smem_bwdg(D), N * C) && colblock_ok(D, W, 0, col_smem_bwdg(D))) m |= 2;
-  return m;
+  if (!opts().sga_tiled || W % 16 != 0 || H % 4 != 0 || N * C > 65535 || opts().wide_scan == 2) return 0;
+  return (!col_wide_ok(D, W, 0, col_smem_bwdg(D), N * C) && colblock_ok(D, W, 0, col_smem_bwdg(D))) ? 1 : 0;
 }
 
 int scan_fwd(const float *x, const float *g, float *A, int N, int C, int D, int H, int W, int dir,
-             hipStream_t st, int tiled = 0)
+             hipStream_t st)
 {
-  if (tiled) {      // (sga_ws_tiled: the column-block kernel is the one that runs; only the alignment is left to check)
-    if (!(aligned16(x) && aligned16(g) && aligned16(A))) return fail(GANET_E_UNSUPPORTED, "SGA: tiled workspace needs 16-byte aligned volumes");
-    return col_fwd(x, g, A, N * C, D, H, W, dir, st, 0, 1);
-  }
   if (col_wide_ok(D, W, dir, col_smem_fwd(D), N * C) && aligned16(x) && aligned16(g) && aligned16(A))
     return col_fwd_wide(x, g, A, N * C, D, H, W, dir, st);
   if (few_lines(N, C, D, H, W, dir)) {
@@ -486,11 +476,7 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
-  if (ndir == 4 && !accumulate && tiled) {
-    if (tiled == 3) GA_LAUNCH((sga_bwd_point<4, false, true, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-    else if (tiled == 1) GA_LAUNCH((sga_bwd_point<4, false, true, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-    else GA_LAUNCH((sga_bwd_point<4, false, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-  }
+  if (ndir == 4 && !accumulate && tiled) GA_LAUNCH((sga_bwd_point<4, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (accumulate) GA_LAUNCH((sga_bwd_point<1, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
@@ -778,7 +764,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
   if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value & 3;
+  else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -825,7 +811,7 @@ GA_EXPORT int ganet_sga_scan_forward_ws(const float *x, const float *g, float *A
   if (dir < 0 || dir > 3) return fail(GANET_E_INVALID, "ganet_sga_scan_forward_ws: dir %d", dir);
   GA_TRY(check_dims5("ganet_sga_scan_forward_ws", N, C, D, H, W));
   const i64 n = (i64)N * C * D * H * W;
-  return scan_fwd(x, g, A_ws + dir * n, N, C, D, H, W, dir, (hipStream_t)stream, dir < 2 && (sga_ws_tiled(N, C, D, H, W) & 1));
+  return scan_fwd(x, g, A_ws + dir * n, N, C, D, H, W, dir, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_sga_backward_scan_ws(const float *g, const uint8_t *mask, const uint16_t *kp, const float *grad_out, float *G_ws,
@@ -836,7 +822,7 @@ GA_EXPORT int ganet_sga_backward_scan_ws(const float *g, const uint8_t *mask, co
   GA_TRY(check_dims5("ganet_sga_backward_scan_ws", N, C, D, H, W));
   const i64 n = (i64)N * C * D * H * W, npix = (i64)N * C * H * W;
   return scan_bwdg(g, mask, kp + dir * npix, grad_out, G_ws + dir * n, N, C, D, H, W, dir, (hipStream_t)stream,
-                   dir < 2 && (sga_ws_tiled(N, C, D, H, W) & 2));
+                   dir < 2 && sga_ws_tiled(N, C, D, H, W));
 }
 
 GA_EXPORT int ganet_sga_workspace_layout(int N, int C, int D, int H, int W)
@@ -856,14 +842,9 @@ GA_EXPORT int ganet_sga_merge(const float *A_ws, float *out, uint8_t *mask, uint
   hipStream_t st = (hipStream_t)stream;
   const i64 HWl = (i64)H * W;
   const bool al = aligned16(A_ws) && aligned16(out) && (((uintptr_t)mask & 3) == 0) && (((uintptr_t)kp & 7) == 0);
-  const bool ta = (sga_ws_tiled(N, C, D, H, W) & 1) != 0;
-  if (ta && !(al && npix / 4 / 64 + 1 < (1ll << 31)))
-    return fail(GANET_E_UNSUPPORTED, "ganet_sga_merge: tiled workspace needs 16-byte aligned volumes");
   if (HWl % 4 == 0 && al && npix / 4 / 64 + 1 < (1ll << 31)) {
-    if (ta) GA_LAUNCH((sga_merge_px4<true>), dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
-                      A_ws + 3 * n, out, mask, kp, D, HWl, npix, W);
-    else GA_LAUNCH((sga_merge_px4<false>), dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
-                   A_ws + 3 * n, out, mask, kp, D, HWl, npix, W);
+    GA_LAUNCH(sga_merge_px4, dim3((unsigned)((npix / 4 + 63) / 64)), dim3(64), st, A_ws, A_ws + n, A_ws + 2 * n,
+              A_ws + 3 * n, out, mask, kp, D, HWl, npix);
     return check_launch("sga merge (4 px / lane)");
   }
   GA_LAUNCH((sga_merge_px<uint8_t>), dim3(px_grid(npix)), dim3(256), st, A_ws, A_ws + n, A_ws + 2 * n,
@@ -883,8 +864,7 @@ GA_EXPORT int ganet_sga_forward(const float *x, const float *g0, const float *g1
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
   // (the four scans on four streams were measured twice and dropped: 0.596 vs 0.606 ms)
-  const int tiled = sga_ws_tiled(N, C, D, H, W);
-  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st, d < 2 && (tiled & 1)));
+  for (int d = 0; d < 4; d++) GA_TRY(scan_fwd(x, gs[d], A_ws + d * n, N, C, D, H, W, d, st));
   return ganet_sga_merge(A_ws, out, mask, kp, N, C, D, H, W, stream);
 }
 
@@ -1003,7 +983,7 @@ GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g
   float *gws[4] = {gw0, gw1, gw2, gw3};
   const int tiled = sga_ws_tiled(N, C, D, H, W);
   for (int d = 0; d < 4; d++)
-    GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st, d < 2 && (tiled & 2)));
+    GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st, d < 2 && tiled));
   (void)gws;
   return ganet_sga_backward_point(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, stream);
 }

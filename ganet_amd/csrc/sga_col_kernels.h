@@ -27,20 +27,24 @@ struct ColGeom {
   int D, H, W;
   i64 HW;
   int out_mode;     // forward scans: 0  A = tile;  1  A = max(A, tile) (running direction max, inference path)
-  int tiled;        // the RESULT volume has the private tiled layout below (directional / adjoint volumes of ganet_sga_forward / _backward)
+  int tiled;        // adjoint scans: the result volume G has the private tiled layout below
 };
 
-// ---- private tiled layout of the vertical directions' volumes ------------------------------------------------------------------
+// ---- private tiled layout of the vertical directions' ADJOINT volumes -------------------------------------------------------------
 // What limits the column scans at the benchmark size is the pattern of their result stores: per batch a block writes D x 4 runs
 // of 64 bytes (16 columns of one plane row) with an 832-byte row pitch -- 3.1 - 3.5 TB/s where a linear fill reaches 4.4 - 5.0
-// (profiles/r3c_*, r3d_*).  The four directional volumes A_dir and the four adjoint volumes G_dir are PRIVATE to SgaFunction
-// (they exist between ganet_sga_forward and ganet_sga_backward only), so the two vertical directions keep theirs tiled:
+// (profiles/r3c_*, r3d_*).  The adjoint volumes G_dir are PRIVATE to ganet_sga_backward (written by the adjoint scans, read by
+// sga_bwd_point, gone afterwards), so the two vertical directions keep theirs tiled:
 //     element (s, d, h, w)  ->  ((((s * NCB + w / 16) * NRB + h / 4) * D + d) * 4 + h % 4) * 16 + w % 16,   NCB = W / 16, NRB = H / 4
 // i.e. [slice][column block][row batch][d][4 rows][16 columns]: a block's batch is ONE contiguous burst of D * 256 bytes, a
 // thread's 16-byte piece lands at 16 * tid.  Same size as the API layout (needs W % 16 == 0 and H % 4 == 0; otherwise the
-// volume stays in the API layout).  Readers: sga_merge_px4<true> and sga_bwd_point<.., TA, TG> (64-byte runs per plane:
-// reads tolerate them, stores do not).  Timing experiment that motivated it: profiles/r7a_ab_sga_stages.txt -- column forward scans
-// 72 -> 61 us, adjoint 98 -> 82 us with tiled result stores.
+// volume stays in the API layout).  Measured (profiles/r7b_* ... r7e_*, same box): column adjoint scans 98 -> 84 us each,
+// sga_bwd_point (which now reads 64-byte runs of G_down / G_up) 283 -> 291, the whole step -1.1 %.
+// The same layout for the directional volumes A_down / A_up of the FORWARD was built and measured as well, and removed: the
+// column forward scans gain only 5.5 us each, and the merge, which runs at ~6 TB/s on 1 KB runs, loses 35 us on 64-byte runs
+// (53 us with a tile-congruent pixel mapping, whose API-layout streams then break into 256-byte pieces; +2.9 % on the step with
+// non-temporal loads, which let a line go before its second row is asked for): whole step +2.0 %.  Reads of a latency-bound
+// kernel tolerate the short runs, a kernel near the fabric's rate does not.
 GA_DEV i64 col_tiled_off(int s, int ncb, int cb, int H, int D, int d, int row)
 {
   return ((((i64)s * ncb + cb) * (H >> 2) + (row >> 2)) * D + d) * 64 + (row & 3) * 16;

@@ -538,9 +538,10 @@ struct PointArgs {
 #ifndef GA_POINT_WAVES
 #define GA_POINT_WAVES 5
 #endif
-// TA / TG: the forward / adjoint volumes of the two vertical directions (pa.dir < 2) have the private tiled layout
-// (sga_col_kernels.h): plane stride 64 instead of H W, the pixel's offset and that of its previous scan position computed once.
-template <int NDIR, bool ACC, bool TA = false, bool TG = false>
+// TG: the ADJOINT volumes of the two vertical directions (G_down, G_up) have the private tiled layout of sga_col_kernels.h:
+// plane stride 64 instead of H W, the pixel's offset computed once; 64-byte runs per plane, which this kernel's reads tolerate
+// (+10 us of 290; the column adjoint scans gain 31 us from writing them as bursts, profiles/r7e_ab_sga_stages.txt).
+template <int NDIR, bool ACC, bool TG = false>
 __global__ void __launch_bounds__(256, GA_POINT_WAVES)
 sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa,
               int D, int H, int W, i64 npix)
@@ -561,9 +562,9 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
     const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
     const i64 vb = s * D * HW + pix;
     const i64 gbo = s * 5 * HW + pix;
-    // tiled volumes: offset of (s, plane 0, h, w); a vertical neighbour is 16 elements away inside a row batch, D * 64 - 48 across
+    // tiled volumes: offset of (s, plane 0, h, w)
     i64 tb = 0;
-    if (TA || TG) tb = (((s * (W >> 4) + (w >> 4)) * (H >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
+    if (TG) tb = (((s * (W >> 4) + (w >> 4)) * (H >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
     float w0[NDIR], w2[NDIR], w3[NDIR];
     int poff[NDIR];          // previous position in forward order (0 = none, see hpm)
     unsigned hpm = 0;        // bit q: direction q has a previous position at this pixel
@@ -578,16 +579,12 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
       // down: h-1, up: h+1, right: w-1, left: w+1
       const bool hp = dir == 0 ? h > 0 : dir == 1 ? h + 1 < H : dir == 2 ? w > 0 : w + 1 < W;
       poff[q] = hp ? (dir == 0 ? -W : dir == 1 ? W : dir == 2 ? -1 : 1) : 0;
-      static_assert(!(TA || TG) || NDIR == 4, "tiled volumes: the four-direction launch only (direction q in slot q)");
-      if (TA && q < 2 && hp) {
-        if (dir == 0) poff[q] = (h & 3) ? -16 : -(D * 64) + 48;          // row h - 1
-        else poff[q] = (h & 3) != 3 ? 16 : D * 64 - 48;                  // row h + 1
-      }
+      static_assert(!TG || NDIR == 4, "tiled adjoint volumes: the four-direction launch only (direction q in slot q)");
       hpm |= hp ? (1u << q) : 0u;
       s0[q] = s1[q] = s2[q] = s3[q] = sg[q] = 0.f;
       mx[q] = -INFINITY;
       a_m[q] = 0.f;
-      a_0[q] = pa.A[q][(TA && q < 2 ? tb : vb) + poff[q]];
+      a_0[q] = pa.A[q][vb + poff[q]];
     }
     constexpr int DU = GA_POINT_DU;
     for (int dc = 0; dc < D; dc += DU) {
@@ -601,14 +598,13 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
         const i64 o = vb + (i64)(d < D ? d : D - 1) * HW;
         const i64 on = vb + (i64)(d + 1 < D ? d + 1 : D - 1) * HW;
         const i64 ot = tb + (i64)(d < D ? d : D - 1) * 64;
-        const i64 otn = tb + (i64)(d + 1 < D ? d + 1 : D - 1) * 64;
         xv[u] = stream_load<(GA_NT_LOADS & 8) != 0>(x + o);
         gxv[u] = ACC ? gradX[o] : 0.f;
 #pragma unroll
         for (int q = 0; q < NDIR; q++) {
           const bool vert = NDIR == 4 && q < 2;      // (the four-direction launch passes direction q in slot q)
           Gv[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.G[q] + ((TG && vert) ? ot : o));
-          Av[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + ((TA && vert) ? otn : on) + poff[q]);     // A[pp][d+1] (used only where d + 1 < D)
+          Av[u][q] = stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + on + poff[q]);                          // A[pp][d+1] (used only where d + 1 < D)
         }
       }
 #pragma unroll
@@ -698,15 +694,10 @@ sga_merge_px(const float *__restrict__ A0, const float *__restrict__ A1, const f
 #ifndef GA_MERGE_DU
 #define GA_MERGE_DU 2      // planes of loads in flight per lane: 1 was best with plain loads (round 1); with the non-temporal loads 2 is (whole step -0.9 ... -1.2 % on two boxes, profiles/r4a_*)
 #endif
-// TA: the two VERTICAL directional volumes (A0, A1) have the private tiled layout of sga_col_kernels.h (W = the image width,
-// W % 16 == 0, H % 4 == 0): the lane's four pixels are 16 contiguous bytes there as well, 64-byte runs per (column block, row)
-// and plane instead of the wave's 1 KB -- which these reads tolerate (measured, profiles/r7b_*), unlike the result stores: a
-// first version gave the wave a tile-congruent pixel set (4 column blocks x 4 rows) and lost 53 us on its API-layout streams.
-template <bool TA>
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const float *__restrict__ A2,
               const float *__restrict__ A3, float *__restrict__ out, uint8_t *__restrict__ mask,
-              uint16_t *__restrict__ kp, int D, i64 HW, i64 npix, int W)
+              uint16_t *__restrict__ kp, int D, i64 HW, i64 npix)
 {
   constexpr int DU = GA_MERGE_DU;
   const i64 nq = npix >> 2;
@@ -715,11 +706,6 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
     const i64 pidx = qidx << 2;
     const i64 s = pidx / HW, pix = pidx - s * HW;
     const i64 vb = s * D * HW + pix;
-    i64 tb = 0;            // tiled volumes: offset of the quad at plane 0, plane stride 64
-    if (TA) {
-      const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
-      tb = (((s * (W >> 4) + (w >> 4)) * (int)((HW / W) >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
-    }
     float m[4][4];
     int k[4][4];
 #pragma unroll
@@ -732,12 +718,8 @@ sga_merge_px4(const float *__restrict__ A0, const float *__restrict__ A1, const 
       for (int u = 0; u < DU; u++) {
         const int d = dc + u < D ? dc + u : D - 1;
         const i64 o = vb + (i64)d * HW;
-        const i64 o01 = TA ? tb + (i64)d * 64 : o;
-        // (tiled volumes: plain loads -- a 128-byte line there holds the same 16 columns of TWO rows, i.e. two different
-        // waves' 64-byte runs; a non-temporal load lets the line go before the second one arrives and it is fetched twice:
-        // the whole step +2.9 % with them, profiles/r7c_ab_step.txt)
-        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0 && !TA>(reinterpret_cast<const f4 *>(A0 + o01));
-        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0 && !TA>(reinterpret_cast<const f4 *>(A1 + o01));
+        a[u][0] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A0 + o));
+        a[u][1] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A1 + o));
         a[u][2] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A2 + o));
         a[u][3] = stream_load<(GA_NT_LOADS & 1) != 0>(reinterpret_cast<const f4 *>(A3 + o));
       }

@@ -61,10 +61,11 @@ int ganet_sga_forward(const float *x, const float *g0, const float *g1, const fl
                       int N, int C, int D, int H, int W, void *stream);
 
 /* The steps of ganet_sga_forward / ganet_sga_backward as they run inside those calls: direction `dir`'s scan into its place in
- * the op's PRIVATE workspace (A_ws / G_ws: [4][N*C*D*H*W] floats; kp: the whole [4][N*C*H*W] array).  The workspace is not in
- * the API layout in general: ganet_sga_workspace_layout() says which of its volumes are tiled for these dimensions (bit 0:
- * A_down / A_up, bit 1: G_down / G_up; element (s, d, h, w) at ((((s * W/16 + w/16) * H/4 + h/4) * D + d) * 4 + h%4) * 16 + w%16).
- * ganet_sga_scan_forward / ganet_sga_backward_scan (above) always write the API layout.
+ * the op's PRIVATE workspace (A_ws / G_ws: [4][N*C*D*H*W] floats; kp: the whole [4][N*C*H*W] array).  A_ws holds the four
+ * directional volumes in the API layout.  G_ws is not in the API layout in general: ganet_sga_workspace_layout() returns 1 if
+ * the two vertical directions' adjoint volumes are tiled for these dimensions (element (s, d, h, w) of G_ws[dir < 2] at
+ * ((((s * W/16 + w/16) * H/4 + h/4) * D + d) * 4 + h%4) * 16 + w%16), 0 if everything has the API layout.
+ * ganet_sga_backward_scan (above) always writes the API layout.
  * Replaces: the same reference code as ganet_sga_scan_forward / ganet_sga_backward_scan. */
 int ganet_sga_scan_forward_ws(const float *x, const float *g, float *A_ws,
                               int N, int C, int D, int H, int W, int dir, void *stream);

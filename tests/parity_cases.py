@@ -116,13 +116,7 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
     per_dir=False skips the cross-check of the per-direction entry point (large volumes)."""
     N, C, D, H, W = x.shape
     dx, dg, A, out, mask, kp = run_sga_forward(api, dev, x, gs)
-    layout = api.query("ganet_sga_workspace_layout", N, C, D, H, W)      # bit 0: A_down / A_up tiled, bit 1: G_down / G_up
     hA = dev.host(A)
-    if layout & 1:
-        hA = hA.copy()
-        for d in range(2):
-            hA[d] = untile_ws(hA[d])
-        per_dir = False          # (ganet_sga_backward_dir takes an API-layout volume)
     for d in range(4):
         if f"A{d}" in want:
             assert np.array_equal(hA[d], want[f"A{d}"]), f"A{d}"
@@ -148,7 +142,7 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
         dev.sync()
         assert np.abs(dev.host(gw1) - dev.host(gw[d])).max() <= 1e-6
     assert np.abs(dev.host(gx1) - dev.host(gx)).max() <= 1e-5
-    if True:
+    if per_dir:
         # ABI 8: the composite entries are their steps -- 4 x scan + ganet_sga_merge, 4 x adjoint scan +
         # ganet_sga_backward_point -- bit for bit (bench.py times the steps in place)
         A2, out2 = dev.empty((4,) + x.shape), dev.empty(x.shape)
@@ -167,6 +161,16 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
         api.call("ganet_sga_backward_point", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(G2), dev.ptr(gx2),
                  *[dev.ptr(g) for g in gw2], N, C, D, H, W, dev.stream)
         dev.sync()
+        # the adjoint volumes themselves: the vertical directions' may be tiled in the private workspace
+        hG, hG2 = dev.host(G), dev.host(G2)
+        assert np.array_equal(hG, hG2)
+        if api.query("ganet_sga_workspace_layout", N, C, D, H, W):
+            G3 = dev.empty(x.shape)
+            for d in range(2):
+                api.call("ganet_sga_backward_scan", dev.ptr(dg[d]), dev.ptr(mask), dev.ptr(kp) + 2 * d * (N * C * H * W), dev.ptr(dgo),
+                         dev.ptr(G3), N, C, D, H, W, d, dev.stream)
+                dev.sync()
+                assert np.array_equal(untile_ws(hG[d]), dev.host(G3)), f"tiled adjoint volume of direction {d}"
         assert np.array_equal(dev.host(gx2), dev.host(gx))
         for d in range(4):
             assert np.array_equal(dev.host(gw2[d]), dev.host(gw[d]))

@@ -167,12 +167,14 @@ def test_full_size_cfg2_against_oracle(api, dev, port_oracle):
     print("cfg2 LGA2 max-abs errors:", err)
 
 
-@pytest.mark.parametrize("tiled", [1, 2, 3])
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 32, 65, 80, 208), (1, 4, 33, 8, 48), (2, 3, 48, 12, 80), (1, 2, 9, 4, 16)])
 def test_sga_tiled_private_workspace(api, dev, port_oracle, shape, tiled):
-    """GANET_SGA_TILED (sga_col_kernels.h): the vertical directions' volumes of SgaFunction's private workspace tiled
-    [slice][W/16][H/4][D][4][16] -- written by the column scans, read by sga_merge_px4_t / sga_bwd_point<.., TA, TG>.  Outputs,
-    mask and arg-max bit-exact, gradients within 1e-4, at the full cfg2 size and at sizes with one / three / five column blocks."""
+    """GANET_SGA_TILED (sga_col_kernels.h): the vertical directions' ADJOINT volumes of ganet_sga_backward's private workspace
+    tiled [slice][W/16][H/4][D][4][16] -- written by the column adjoint scans as contiguous bursts, read by
+    sga_bwd_point<.., TG>.  Both settings: same gradients (within 1e-4 of the oracle), and the tiled volume itself, un-tiled by
+    the checker, equals what ganet_sga_backward_scan writes in the API layout.  Shapes: several row batches, one to five column
+    blocks, depths that do and do not fill their lanes (GPU: the full cfg2 size as well)."""
     was = api.get_option("GANET_SGA_TILED")
     api.set_option("GANET_SGA_TILED", tiled)
     try:
