@@ -176,7 +176,7 @@ _FAMILY_KERNELS = {
     "sga_merge_argmax": [["sga_merge_px4"]],
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true, true>"], ["sga_col_bwdg<5, true, true, true>"],
                      ["sga_row_bwdg<2, 32, 4, 1, true, false, 64, 9>"], ["sga_row_bwdg<2, 32, 4, 1, false, false, 64, 9>"]],
-    "sga_bwd_point": [["sga_bwd_point<4, false>"]],
+    "sga_bwd_point": [["sga_bwd_point<4, false, true>|sga_bwd_point<4, false>|sga_bwd_point<4, false, false>"]],   # (a|b: first name found)
     "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_xp<2, 3, 0>", "lga_apply_pp_xo<2, true, false>"],
                                          ["lga_filter_grad_pp_gypx<2, 3, 0>", "lga_apply_pp_pi<2, true, false>"]],
     "lga_apply (fwd pass)": [["lga_apply_pp_xo<2, false, false>"], ["lga_apply_pp_pi<2, false, false>"]],
@@ -220,8 +220,10 @@ def _family_traffic(name, kern):
     tot, n = 0, 0
     for launch in _FAMILY_KERNELS[name]:
         try:
-            tot += sum(kern[k]["read_bytes"] + kern[k]["write_bytes"] for k in launch)
-        except KeyError:
+            for spec in launch:
+                k = next(n for n in spec.split("|") if n in kern)
+                tot += kern[k]["read_bytes"] + kern[k]["write_bytes"]
+        except StopIteration:
             return None
         n += 1
     return int(tot / n)

@@ -1,5 +1,7 @@
 """Runs ONE stage of the hot path a few times (for rocprofv3 --pmc / --kernel-trace runs).
-python scripts/prof_stage.py <stage> [iters]   stage in: sga_fwd_v sga_fwd_h sga_bwd_v sga_bwd_h sga_fwd sga_bwd lga_fwd lga_bwd lga_api all"""
+python scripts/prof_stage.py <stage> [iters]   stage in: sga_fwd_v sga_fwd_h sga_bwd_v sga_bwd_h sga_fwd sga_bwd lga_fwd lga_bwd lga_api all step
+(step = exactly the 16 launches of one benchmark step, the private workspaces as the Functions keep them: what the PMC passes
+behind profiles/traffic_pmc.json run)"""
 import os
 import sys
 
@@ -63,15 +65,15 @@ for _ in range(iters):
         bwd(0)
     if stage in ("sga_bwd_h", "all"):
         bwd(2)
-    if stage in ("sga_fwd", "all"):
+    if stage in ("sga_fwd", "all", "step"):
         fullfwd()
-    if stage in ("sga_bwd", "all"):
+    if stage in ("sga_bwd", "all", "step"):
         fullbwd()
     # LGA2 as Lga2Function runs it (pair-interleaved private intermediate and intermediate gradient)
-    if stage in ("lga_fwd", "all"):
+    if stage in ("lga_fwd", "all", "step"):
         lib.call("ganet_lga_apply_paired", xl.data_ptr(), f.data_ptr(), tp.data_ptr(), B, DL, HL, WL, 2, 0, 0, 1, st)
         lib.call("ganet_lga_apply_paired", tp.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, 2, 0, 1, 0, st)
-    if stage in ("lga_bwd", "all"):
+    if stage in ("lga_bwd", "all", "step"):
         lib.call("ganet_lga_filter_grad_paired", tp.data_ptr(), gy.data_ptr(), gf.data_ptr(), B, DL, HL, WL, 2, 0, 1, 0, st)
         lib.call("ganet_lga_apply_paired", gy.data_ptr(), f.data_ptr(), gtp.data_ptr(), B, DL, HL, WL, 2, 1, 0, 1, st)
         lib.call("ganet_lga_filter_grad_paired", xl.data_ptr(), gtp.data_ptr(), gf.data_ptr(), B, DL, HL, WL, 2, 1, 0, 1, st)
