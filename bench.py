@@ -123,6 +123,7 @@ def stage_timings(inp, iters=5, only=None):
     # LGA2 as Lga2Function runs it: the private intermediate and its gradient pair-interleaved (functions/GANet.py: _LgaChain)
     tp = torch.empty(B * ((DL + 1) // 2) * HL * WL * 2, device=xl.device)
     gtp = torch.empty_like(tp)
+    edge = torch.empty((B, 3, HL, WL), device=xl.device)      # the filters' edge sums: written by the first pass, read by the data-backward launches
     p = lambda t: t.data_ptr()      # noqa: E731
     names = ["down", "up", "right", "left"]
     gp = [p(g) for g in gs]
@@ -136,12 +137,12 @@ def stage_timings(inp, iters=5, only=None):
     calls.append(("sga_bwd_point", lambda: lib.call("ganet_sga_backward_point", p(x), *gp, p(A), p(G), p(gx), *[p(t) for t in gw],
                                                     N, C, D, H, W, st)))
     calls += [
-        ("lga_fwd_apply_1", lambda: lib.call("ganet_lga_apply_paired", p(xl), p(f), p(tp), B, DL, HL, WL, RADIUS, 0, 0, 1, st)),
+        ("lga_fwd_apply_1", lambda: lib.call("ganet_lga_apply_paired_edges", p(xl), p(f), p(tp), p(edge), B, DL, HL, WL, RADIUS, 0, 0, 1, st)),
         ("lga_fwd_apply_2", lambda: lib.call("ganet_lga_apply_paired", p(tp), p(f), p(y), B, DL, HL, WL, RADIUS, 0, 1, 0, st)),
         ("lga_bwd_filter_grad_2", lambda: lib.call("ganet_lga_filter_grad_paired", p(tp), p(gy), p(gf), B, DL, HL, WL, RADIUS, 0, 1, 0, st)),
-        ("lga_bwd_data_2", lambda: lib.call("ganet_lga_apply_paired", p(gy), p(f), p(gtp), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
+        ("lga_bwd_data_2", lambda: lib.call("ganet_lga_apply_paired_edges", p(gy), p(f), p(gtp), p(edge), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
         ("lga_bwd_filter_grad_1", lambda: lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
-        ("lga_bwd_data_1", lambda: lib.call("ganet_lga_apply_paired", p(gtp), p(f), p(gxl), B, DL, HL, WL, RADIUS, 1, 1, 0, st)),
+        ("lga_bwd_data_1", lambda: lib.call("ganet_lga_apply_paired_edges", p(gtp), p(f), p(gxl), p(edge), B, DL, HL, WL, RADIUS, 1, 1, 0, st)),
     ]
     if only is not None:          # (development A/B scripts: one op's kernels, e.g. with a library build that lacks the newer entries)
         calls = [c for c in calls if c[0].startswith(only)]

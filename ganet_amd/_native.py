@@ -40,6 +40,7 @@ _PROTOS = {
     "ganet_lga_backward": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_lga_forward_regress": [_P] * 5 + [_I] * 5 + [_P],
     "ganet_lga_apply_paired": [_P] * 3 + [_I] * 8 + [_P],
+    "ganet_lga_apply_paired_edges": [_P] * 4 + [_I] * 8 + [_P],
     "ganet_lga_filter_grad_paired": [_P] * 3 + [_I] * 8 + [_P],
     "ganet_cost_volume_forward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],

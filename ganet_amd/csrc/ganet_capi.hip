@@ -598,7 +598,7 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
 
 // one LGA pass / data-backward with one side in the pair-interleaved layout (lga_apply_pp_pi / lga_apply_pp_po / lga_apply_pp_xo)
 int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, bool transposed, bool x_paired,
-                      hipStream_t st)
+                      hipStream_t st, float *edge = nullptr)
 {
   if ((i64)H * W >= (1ll << 28) || W % 2 != 0 || !aligned16(x) || !aligned16(y))
     return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: needs W even, planes below 2^28 pixels and 16-byte aligned volumes");
@@ -607,16 +607,16 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   i64 items;
   const LgaSegMix sg = lga_items(W, H, B, D, false, &items);
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: too many tiles");
+  float *const none = nullptr;
+#define L(K, T) GA_LAUNCH((K<2, T>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, none, none, edge)
   if (x_paired) {
-    if (transposed) GA_LAUNCH((lga_apply_pp_pi<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-    else GA_LAUNCH((lga_apply_pp_pi<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    if (transposed) L(lga_apply_pp_pi, true); else L(lga_apply_pp_pi, false);
   } else if (GA_LGA_PLANAR && W % 4 == 0) {      // API-layout input staged planar, two 16-byte copies per plane pair
-    if (transposed) GA_LAUNCH((lga_apply_pp_xo<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-    else GA_LAUNCH((lga_apply_pp_xo<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    if (transposed) L(lga_apply_pp_xo, true); else L(lga_apply_pp_xo, false);
   } else {
-    if (transposed) GA_LAUNCH((lga_apply_pp_po<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
-    else GA_LAUNCH((lga_apply_pp_po<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg);
+    if (transposed) L(lga_apply_pp_po, true); else L(lga_apply_pp_po, false);
   }
+#undef L
   return check_launch("lga apply (plane pairs, interleaved volume)");
 }
 
@@ -1055,16 +1055,34 @@ GA_EXPORT int ganet_lga_forward(const float *x, const float *f, float *y, int B,
   return launch_lga_fwd<3>(x, f, y, B, D, H, W, false, st);
 }
 
+namespace {
+int lga_apply_paired_impl(const char *who, const float *x, const float *f, float *y, float *edge, int B, int D, int H, int W, int radius,
+                          int transposed, int x_paired, int y_paired, void *stream)
+{
+  if (!x || !f || !y) return fail(GANET_E_INVALID, "%s: null pointer", who);
+  if (x == y) return fail(GANET_E_INVALID, "%s: y must not alias x", who);
+  GA_TRY(check_lga(who, B, D, H, W, radius));
+  if (x_paired && y_paired) return fail(GANET_E_INVALID, "%s: at most one of x_paired / y_paired", who);
+  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "%s: radius 2 only", who);
+  if (!x_paired && !y_paired) {
+    if (edge) return fail(GANET_E_UNSUPPORTED, "%s: the edge-sum side channel belongs to the pair-interleaved forms", who);
+    return launch_lga_fwd<2>(x, f, y, B, D, H, W, transposed != 0, (hipStream_t)stream);
+  }
+  return launch_lga_paired(x, f, y, B, D, H, W, transposed != 0, x_paired != 0, (hipStream_t)stream, edge);
+}
+}  // namespace
+
 GA_EXPORT int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, int radius,
                                      int transposed, int x_paired, int y_paired, void *stream)
 {
-  if (!x || !f || !y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: null pointer");
-  if (x == y) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: y must not alias x");
-  GA_TRY(check_lga("ganet_lga_apply_paired", B, D, H, W, radius));
-  if (x_paired && y_paired) return fail(GANET_E_INVALID, "ganet_lga_apply_paired: at most one of x_paired / y_paired");
-  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: radius 2 only");
-  if (!x_paired && !y_paired) return launch_lga_fwd<2>(x, f, y, B, D, H, W, transposed != 0, (hipStream_t)stream);
-  return launch_lga_paired(x, f, y, B, D, H, W, transposed != 0, x_paired != 0, (hipStream_t)stream);
+  return lga_apply_paired_impl("ganet_lga_apply_paired", x, f, y, nullptr, B, D, H, W, radius, transposed, x_paired, y_paired, stream);
+}
+
+GA_EXPORT int ganet_lga_apply_paired_edges(const float *x, const float *f, float *y, float *edge, int B, int D, int H, int W, int radius,
+                                           int transposed, int x_paired, int y_paired, void *stream)
+{
+  if (!edge) return fail(GANET_E_INVALID, "ganet_lga_apply_paired_edges: null edge buffer");
+  return lga_apply_paired_impl("ganet_lga_apply_paired_edges", x, f, y, edge, B, D, H, W, radius, transposed, x_paired, y_paired, stream);
 }
 
 GA_EXPORT int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,

@@ -636,7 +636,9 @@ template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&
 // zero where the tap leaves the image; cmid / sin_m / sin_p as in lga_gather_weights (centre coefficient of the spatially
 // replaced taps, in-range sums of the two outer depth slabs).  One depth slab at a time (scheduling fence in between): left
 // alone, the compiler issues all 125 loads of the transposed gather first and spills their destinations.
-template <int R, bool TRANSPOSED, bool CHECK>
+// OWN_SUMS = false (transposed only): cmid / sin_m / sin_p are given (the forward pass of the same filters wrote them,
+// lga_apply_pp.inc: `edge`), the first of the two sweeps below is skipped.
+template <int R, bool TRANSPOSED, bool CHECK, bool OWN_SUMS = true>
 GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, int ic, int jc,
                              f2 (&wq)[(3 * (2 * R + 1) * (2 * R + 1) + 1) / 2], float &cmid, float &sin_m, float &sin_p)
 {
@@ -665,7 +667,8 @@ GA_DEV void lga_gather_pairs(const float *__restrict__ fb, const LgaGeom &geo, i
     if (dd == 2) sin_p += i2f(f2i(own) & okm);
     return i2f(f2i(own) & okm);
   };
-  if (TRANSPOSED) {
+  static_assert(OWN_SUMS || TRANSPOSED, "untransposed: the own taps ARE the weights");
+  if (TRANSPOSED && OWN_SUMS) {
     // Two sweeps, so that at most ~75 loads are in flight with the 76 weight registers not yet live in the first: (1) the own
     // taps, reduced to the three sums (an interior pixel needs only the two outer slabs: its centre coefficient is zero);
     // (2) the weights proper, tap (-dd, -a, -b) of the neighbour at (+a, +b).  In one sweep the ~125 destinations plus the

@@ -171,14 +171,23 @@ class _LgaChain(Function):
             with torch.cuda.device_of(input):
                 t1p = torch.empty(B * ((D + 1) // 2) * H * W * 2, dtype=input.dtype, device=input.device)
                 y = torch.empty_like(input)
+                # the filters' per-pixel edge sums, a by-product of the first pass kept for the two data-backward launches
+                # (include/ganet_hip.h: ganet_lga_apply_paired_edges); only where a backward will run
+                edge = None
+                if input.requires_grad or filters.requires_grad:
+                    edge = torch.empty((B, 3, H, W), dtype=input.dtype, device=input.device)
                 try:
-                    _lib().call("ganet_lga_apply_paired", _p(input), _p(filters), _p(t1p), B, D, H, W, radius, 0, 0, 1, _stream())
+                    if edge is not None:
+                        _lib().call("ganet_lga_apply_paired_edges", _p(input), _p(filters), _p(t1p), _p(edge), B, D, H, W, radius, 0, 0, 1, _stream())
+                    else:
+                        _lib().call("ganet_lga_apply_paired", _p(input), _p(filters), _p(t1p), B, D, H, W, radius, 0, 0, 1, _stream())
                     _lib().call("ganet_lga_apply_paired", _p(t1p), _p(filters), _p(y), B, D, H, W, radius, 0, 1, 0, _stream())
                     ctx.paired = True
                 except _native.GanetError as e:
                     if e.code != _native.E_UNSUPPORTED:
                         raise
             if ctx.paired:
+                ctx.edge = edge
                 ctx.save_for_backward(filters, input, t1p)
                 return y
         ins = [input]
@@ -208,9 +217,16 @@ class _LgaChain(Function):
                 gt1p, gx = torch.empty_like(t1p), torch.empty_like(x)      # the intermediate's gradient is private too
                 lib, st, r = _lib(), _stream(), ctx.radius
                 lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, r, 0, 1, 0, st)
-                lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1p), B, D, H, W, r, 1, 0, 1, st)
+                edge = getattr(ctx, "edge", None)
+                if edge is not None:
+                    lib.call("ganet_lga_apply_paired_edges", _p(g), _p(filters), _p(gt1p), _p(edge), B, D, H, W, r, 1, 0, 1, st)
+                else:
+                    lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1p), B, D, H, W, r, 1, 0, 1, st)
                 lib.call("ganet_lga_filter_grad_paired", _p(x), _p(gt1p), _p(gradFilters), B, D, H, W, r, 1, 0, 1, st)
-                lib.call("ganet_lga_apply_paired", _p(gt1p), _p(filters), _p(gx), B, D, H, W, r, 1, 1, 0, st)
+                if edge is not None:
+                    lib.call("ganet_lga_apply_paired_edges", _p(gt1p), _p(filters), _p(gx), _p(edge), B, D, H, W, r, 1, 1, 0, st)
+                else:
+                    lib.call("ganet_lga_apply_paired", _p(gt1p), _p(filters), _p(gx), B, D, H, W, r, 1, 1, 0, st)
             return gx, gradFilters, None
         with torch.cuda.device_of(g):
             gradFilters = torch.empty_like(filters)

@@ -175,6 +175,13 @@ int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *s
  * radius 2 only, W even, 16-byte aligned volumes; GANET_E_UNSUPPORTED otherwise (use the API-layout entries). */
 int ganet_lga_apply_paired(const float *x, const float *f, float *y, int B, int D, int H, int W, int radius,
                            int transposed, int x_paired, int y_paired, void *stream);
+/* The same with the per-pixel EDGE SUMS of the filters as a side channel, edge: [B][3][H][W] floats (caller-allocated, private to
+ * the op): the centre coefficient of the spatially replaced taps and the in-range sums of the two outer depth slabs, which
+ * depend on f only.  transposed == 0 (a forward pass): WRITTEN as a by-product (the pass gathers those taps anyway);
+ * transposed == 1 (the data-backward of the same filters): READ, instead of gathering 50 - 75 own taps per pixel for them.
+ * Lga2Function's forward fills it once, its two data-backward launches use it. */
+int ganet_lga_apply_paired_edges(const float *x, const float *f, float *y, float *edge, int B, int D, int H, int W, int radius,
+                                 int transposed, int x_paired, int y_paired, void *stream);
 
 /* ABI v7.  The filter gradient of one LGA pass (the first half of ganet_lga_backward: lga_filter_backward,
  * GANet_kernel.cu:1177-1216) with x OR gy in the pair-interleaved layout (see ganet_lga_apply_paired; at most one of

@@ -31,6 +31,7 @@ t1, gxl = torch.empty_like(xl), torch.empty_like(xl)
 gf = torch.empty_like(f)
 tp = torch.empty(B * ((DL + 1) // 2) * HL * WL * 2, device=xl.device)
 gtp = torch.empty_like(tp)
+edge = torch.empty((B, 3, HL, WL), device=xl.device)
 lib.call("ganet_sga_forward", x.data_ptr(), *[g.data_ptr() for g in gs], A.data_ptr(), out.data_ptr(), mask.data_ptr(),
          kp.data_ptr(), N, C, D, H, W, st)
 torch.cuda.synchronize()
@@ -71,13 +72,13 @@ for _ in range(iters):
         fullbwd()
     # LGA2 as Lga2Function runs it (pair-interleaved private intermediate and intermediate gradient)
     if stage in ("lga_fwd", "all", "step"):
-        lib.call("ganet_lga_apply_paired", xl.data_ptr(), f.data_ptr(), tp.data_ptr(), B, DL, HL, WL, 2, 0, 0, 1, st)
+        lib.call("ganet_lga_apply_paired_edges", xl.data_ptr(), f.data_ptr(), tp.data_ptr(), edge.data_ptr(), B, DL, HL, WL, 2, 0, 0, 1, st)
         lib.call("ganet_lga_apply_paired", tp.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, 2, 0, 1, 0, st)
     if stage in ("lga_bwd", "all", "step"):
         lib.call("ganet_lga_filter_grad_paired", tp.data_ptr(), gy.data_ptr(), gf.data_ptr(), B, DL, HL, WL, 2, 0, 1, 0, st)
-        lib.call("ganet_lga_apply_paired", gy.data_ptr(), f.data_ptr(), gtp.data_ptr(), B, DL, HL, WL, 2, 1, 0, 1, st)
+        lib.call("ganet_lga_apply_paired_edges", gy.data_ptr(), f.data_ptr(), gtp.data_ptr(), edge.data_ptr(), B, DL, HL, WL, 2, 1, 0, 1, st)
         lib.call("ganet_lga_filter_grad_paired", xl.data_ptr(), gtp.data_ptr(), gf.data_ptr(), B, DL, HL, WL, 2, 1, 0, 1, st)
-        lib.call("ganet_lga_apply_paired", gtp.data_ptr(), f.data_ptr(), gxl.data_ptr(), B, DL, HL, WL, 2, 1, 1, 0, st)
+        lib.call("ganet_lga_apply_paired_edges", gtp.data_ptr(), f.data_ptr(), gxl.data_ptr(), edge.data_ptr(), B, DL, HL, WL, 2, 1, 1, 0, st)
     if stage in ("lga_api", "all"):                      # one pass on the API layout (LgaFunction; mixed item list)
         lib.call("ganet_lga_forward", xl.data_ptr(), f.data_ptr(), t1.data_ptr(), B, DL, HL, WL, 2, st)
         lib.call("ganet_lga_backward", xl.data_ptr(), f.data_ptr(), gy.data_ptr(), gxl.data_ptr(), gf.data_ptr(),

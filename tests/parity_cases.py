@@ -260,6 +260,26 @@ def check_lga2_paired(api, dev, x, f, gy, r, passes, want):
     err = {"y": float(np.abs(dev.host(y) - want["y"]).max()), "gx": float(np.abs(dev.host(gx) - want["gx"]).max()),
            "gf": float(np.abs(dev.host(gf) - want["gf"]).max())}
     assert max(err.values()) <= TOL, err
+    # The same chain with the filters' edge sums as a side channel (ganet_lga_apply_paired_edges, what Lga2Function runs when a
+    # backward will follow): written by the first pass, read by both data-backward launches.  The sums are the same loads added
+    # in the same order on either side, so every result is bit-identical; the buffer itself is checked against its definition.
+    edge = dev.empty((B, 3, H, W))
+    t1e, gt1e, gxe = dev.empty(pshape), dev.empty(pshape), dev.empty(x.shape)
+    api.call("ganet_lga_apply_paired_edges", dev.ptr(dx), dev.ptr(df), dev.ptr(t1e), dev.ptr(edge), B, D, H, W, 2, 0, 0, 1, dev.stream)
+    api.call("ganet_lga_apply_paired_edges", dev.ptr(dgy), dev.ptr(df), dev.ptr(gt1e), dev.ptr(edge), B, D, H, W, 2, 1, 0, 1, dev.stream)
+    api.call("ganet_lga_apply_paired_edges", dev.ptr(gt1e), dev.ptr(df), dev.ptr(gxe), dev.ptr(edge), B, D, H, W, 2, 1, 1, 0, dev.stream)
+    dev.sync()
+    assert np.array_equal(dev.host(t1e), dev.host(t1p)) and np.array_equal(dev.host(gt1e), dev.host(gt1p))
+    assert np.array_equal(dev.host(gxe), dev.host(gx))
+    he = dev.host(edge)
+    inside = np.zeros((25, H, W), bool)
+    for a in range(-2, 3):
+        for b in range(-2, 3):
+            ii, jj = np.arange(H)[:, None] + a, np.arange(W)[None, :] + b
+            inside[(a + 2) * 5 + (b + 2)] = (ii >= 0) & (ii < H) & (jj >= 0) & (jj < W)
+    f3 = f.reshape(B, 3, 25, H, W)
+    want_edge = np.stack([(f3 * ~inside).sum((1, 2)), (f3[:, 0] * inside).sum(1), (f3[:, 2] * inside).sum(1)], 1)
+    assert np.abs(he - want_edge).max() <= 1e-5, float(np.abs(he - want_edge).max())
     return err
 
 
