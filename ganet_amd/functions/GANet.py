@@ -174,7 +174,7 @@ class _LgaChain(Function):
                 # the filters' per-pixel edge sums, a by-product of the first pass kept for the two data-backward launches
                 # (include/ganet_hip.h: ganet_lga_apply_paired_edges); only where a backward will run
                 edge = None
-                if input.requires_grad or filters.requires_grad:
+                if (input.requires_grad or filters.requires_grad) and os.environ.get("GANET_LGA_EDGES", "1") != "0":
                     edge = torch.empty((B, 3, H, W), dtype=input.dtype, device=input.device)
                 try:
                     if edge is not None:

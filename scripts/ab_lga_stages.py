@@ -6,12 +6,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, bench
 from ganet_amd import _native
+DEFAULTS = {}
 for rep in range(2):
     for name in sys.argv[1:]:
         libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value
         _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
-        try:
-            _native._LIB.set_option("GANET_SGA_TILED", 0)  # options are process-wide in the library: back to off unless asked for
+        try:                                               # options are process-wide in a loaded library: start from its own defaults
+            if libname not in DEFAULTS:
+                DEFAULTS[libname] = _native._LIB.get_option("GANET_SGA_TILED")
+            _native._LIB.set_option("GANET_SGA_TILED", DEFAULTS[libname])
         except Exception:
             pass
         for kv in filter(None, optstr.split(",")):

@@ -12,18 +12,23 @@ from ganet_amd import _native
 
 dev = torch.device("cuda:0")
 graphs = {}
+DEFAULTS = {}
 inp = bench.make_inputs(dev)
 pool = torch.cuda.graph_pool_handle()
 for idx, name in enumerate(sys.argv[1:]):
     libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value: ganet_set_option before the capture
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
+    os.environ.pop("GANET_LGA_EDGES", None)
+    # options are process-wide in a loaded library: every entry starts from that library's own defaults
     try:
-        _native._LIB.set_option("GANET_SGA_TILED", 0)              # RESET_OPTS: options are process-wide in the library: back to off unless asked for
+        if libname not in DEFAULTS:
+            DEFAULTS[libname] = _native._LIB.get_option("GANET_SGA_TILED")
+        _native._LIB.set_option("GANET_SGA_TILED", DEFAULTS[libname])
     except Exception:
         pass
     for kv in filter(None, optstr.split(",")):
         k, v = kv.split("=")
-        if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE"):      # read by the Python layer from the environment at every call
+        if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE", "GANET_LGA_EDGES"):      # read by the Python layer from the environment at every call
             os.environ[k] = v
         else:
             _native._LIB.set_option(k, int(v))
