@@ -461,6 +461,7 @@ GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
   hipsim::dma_issue(slot + lane, gsrc, 1);
 #else
   (void)lane;
+  __builtin_assume(slot != nullptr);      // (a generic -> LDS address cast otherwise carries a null test: two scalar instructions per batch)
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
   asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" GA_M0_RESTORE_ASM
@@ -612,6 +613,7 @@ template <int ND> GA_DEV void lga_dma4p_all(const float *base, const unsigned (&
                       reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + (LGAP_IMM_OFFSET ? 256 * k : 0)), 1);
 #else
   (void)lane;
+  __builtin_assume(slot != nullptr);      // (a generic -> LDS address cast otherwise carries a null test: two scalar instructions per batch)
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
   static_assert(ND == 5 || ND == 7 || ND == 10, "copy batch written out for R = 1, 2, 3");
@@ -722,6 +724,7 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
     hipsim::dma_issue(slot + k * 256 + 4 * lane, reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + o[k] + 1024 * k), 4);
 #else
   (void)lane;
+  __builtin_assume(slot != nullptr);      // (a generic -> LDS address cast otherwise carries a null test: two scalar instructions per batch)
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
   asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\t"
@@ -865,6 +868,7 @@ GA_DEV void lga_dma4s(const float *base, unsigned off, float *slot, int lane)
   hipsim::dma_issue(slot + lane, reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off), 1);
 #else
   (void)lane;
+  __builtin_assume(slot != nullptr);      // (a generic -> LDS address cast otherwise carries a null test: two scalar instructions per batch)
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
   unsigned keep;
   asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %3, %2" GA_M0_RESTORE_ASM

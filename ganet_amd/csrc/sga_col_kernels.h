@@ -15,9 +15,6 @@
 //     computed and land in LDS after it, so the memory latency hides behind the compute.
 // Arithmetic (fwd_step / bwdg_step) is shared with sga_kernels.h: bit-exact forward.
 #pragma once
-#ifndef GA_COL_TILED_ABLATE
-#define GA_COL_TILED_ABLATE 0      // development only (timing): bit 1 the column adjoint reads its mask as if it were tiled too
-#endif
 #include "ga_common.h"
 #include "sga_kernels.h"
 
