@@ -162,27 +162,7 @@ def stage_timings(inp, iters=5, only=None):
         for i in range(len(calls)):
             acc[i] += ev[i].elapsed_time(ev[i + 1])
     res = {name: a / iters for (name, _), a in zip(calls, acc)}
-    # What an interval holds besides its kernel: the event record and the launch gap between two dependent launches.  Calibrated
-    # in the same way with a kernel that does next to nothing (the merge on a one-plane, four-pixel volume: one wavefront): the
-    # median interval of 16 such launches.  Sum of the raw intervals exceeds the hipGraph replay of the same 16 kernels by
-    # 16 x this (profiles/r7n_diag_fg_step_vs_stage_timing.txt).
-    tA = torch.zeros(4 * 4, device=x.device)
-    tO, tM, tK = torch.empty(4, device=x.device), torch.empty(4, dtype=torch.uint8, device=x.device), torch.empty(16, dtype=torch.int16, device=x.device)
-    tiny = lambda: lib.call("ganet_sga_merge", p(tA), p(tO), p(tM), p(tK), 1, 1, 1, 1, 4, st)      # noqa: E731
-    for _ in range(4):
-        tiny()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(17)]
-    ev[0].record()
-    for i in range(16):
-        tiny()
-        ev[i + 1].record()
-    ev[-1].synchronize()
-    gaps = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(16))
-    overhead = gaps[8]
-    res["event_interval_overhead"] = overhead
-    res["step_sum_of_kernels"] = sum(v for k, v in res.items() if k != "event_interval_overhead")
-    res["step_sum_of_kernels_net"] = res["step_sum_of_kernels"] - len(calls) * overhead
+    res["step_sum_of_kernels"] = sum(res.values())
     if only is not None and only != "lga":
         return res
     # per PASS, as earlier rounds reported the LGA2 chain (mean of its two passes)
@@ -270,14 +250,9 @@ def roofline_from_stages(stages):
     kern = pmc_traffic()
     table, best, best_t = [], None, -1.0
     unit_traffic = 0
-    # every interval of stage_timings holds one kernel plus the event / launch overhead calibrated there: the families are net of
-    # it (an LGA pass = two kernels backward, one forward: `ovh` intervals per launch of the family)
-    ovh = stages.get("event_interval_overhead", 0.0)
-    per_launch = {"lga_apply+filter_grad (bwd pass)": 2}
     for name, (keys, bytes_per_launch, mult) in fam.items():
-        n_int = per_launch.get(name, 1)
-        avg_ms = sum(stages[k] for k in keys) / len(keys) - n_int * ovh
-        step_ms = (sum(stages[k] for k in keys) - len(keys) * n_int * ovh) * mult
+        avg_ms = sum(stages[k] for k in keys) / len(keys)
+        step_ms = sum(stages[k] for k in keys) * mult
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = _family_traffic(name, kern)
         row = {"kernel": name, "launches_per_step": len(keys) * mult, "avg_launch_ms": round(avg_ms, 4),
@@ -313,9 +288,7 @@ def roofline_from_stages(stages):
         out["unit_traffic_bytes"] = int(unit_traffic)
         out["unit_traffic_ratio"] = round(unit_traffic / UNIT_BYTES, 3)
     out["timing"] = ("every kernel of the step timed in place (HIP events between consecutive launches of one in-order pass over "
-                     "the step's 16 launches): stage_ms holds the raw intervals, avg_launch_ms / step_ms are net of "
-                     "stage_ms.event_interval_overhead (the same interval around a one-wavefront kernel); no family is a "
-                     "difference of other kernels' measurements")
+                     "the step's 16 launches): stage_ms; no family is a difference of other measurements")
     out["mfma"] = MFMA_NOTE
     out["achievable"] = ACHIEVABLE
     return out
