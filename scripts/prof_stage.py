@@ -14,6 +14,8 @@ from ganet_amd import _native  # noqa: E402
 
 stage = sys.argv[1] if len(sys.argv) > 1 else "all"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if os.environ.get("GANET_PROF_LIB"):      # (development: a tagged build of the library, scripts/build_variants.py)
+    _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", os.environ["GANET_PROF_LIB"]))
 lib = _native.lib()
 inp = bench.make_inputs(torch.device("cuda:0"))
 x, gs, go, xl, f, gy = [t.detach() if torch.is_tensor(t) else [u.detach() for u in t] for t in inp]
