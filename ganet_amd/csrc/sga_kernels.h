@@ -554,7 +554,13 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
   const i64 HW = (i64)H * W;
   const i64 stride = (i64)gridDim.x * blockDim.x;
 #ifndef GA_POINT_XCD
-#define GA_POINT_XCD 0      // 1: XCD-aware block order (neighbouring blocks share the lines of the one-pixel-shifted reads); A/B builds
+// XCD-aware block order: neighbouring blocks on one XCD's L2.  Round 3 (API-layout volumes only): the kernel alone 0.332 -> 0.304
+// ms, the step unchanged -- left off.  Round 4, with the vertical adjoint volumes tiled: a 128-byte line of those holds the same
+// 16 columns of TWO rows, i.e. the 64-byte runs of two waves a row apart (0.8 blocks); round-robin over the XCDs each of them
+// fetched the line into an L2 of its own: 1.57 GB read per launch, 1.30 GB with this order (profiles/r7r_pmc_point_block_order.txt)
+// at the same time (+-0.1 % on the step, profiles/r7l_*: the kernel is bound by load latency, not by the fabric) -- on for the
+// traffic.
+#define GA_POINT_XCD 1
 #endif
   const int bid = GA_POINT_XCD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   for (i64 pidx = (i64)bid * blockDim.x + threadIdx.x; pidx < npix; pidx += stride) {
