@@ -58,16 +58,12 @@ int check_launch(const char *what)
 // One default path per operator (measured on MI355X, profiles/) plus its general fallback; the knobs exist so that tests can
 // reach the fallbacks and the forced modes.  Fields are atomics: ganet_set_option() may race with launches on other threads
 // (each launcher reads a field once).
-#ifndef GA_SGA_POINT2_DEFAULT
-#define GA_SGA_POINT2_DEFAULT 0
-#endif
 #ifndef GA_SGA_TILED_DEFAULT
 #define GA_SGA_TILED_DEFAULT 1
 #endif
 struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
-  std::atomic<int> point2{GA_SGA_POINT2_DEFAULT};    // SGA backward: the per-pixel kernel with two pixels per lane (W even, 8-byte aligned volumes)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
@@ -87,7 +83,6 @@ void load_env_options()
   };
   geti("GANET_LGA_WAVE", g_opt.lga_wave);
   geti("GANET_SGA_TILED", g_opt.sga_tiled);
-  geti("GANET_SGA_POINT2", g_opt.point2);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
@@ -481,18 +476,6 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
-  // two pixels per lane where the layout allows it (W even, 8-byte aligned volumes): sga_kernels.h: sga_bwd_point2
-  bool al8 = W % 2 == 0 && (((uintptr_t)x | (uintptr_t)gx) & 7) == 0;
-  for (int q = 0; q < 4 && al8; q++)
-    al8 = ((((uintptr_t)pa.G[q] | (uintptr_t)pa.A[q] | (uintptr_t)pa.g[q] | (uintptr_t)pa.gw[q]) & 7) == 0);
-  if (ndir == 4 && !accumulate && al8 && opts().point2) {
-    i64 g2 = (npix / 2 + pb - 1) / pb;
-    if (g2 > gmax) g2 = gmax;
-    if (g2 < 1) g2 = 1;
-    if (tiled) GA_LAUNCH((sga_bwd_point2<true>), dim3((unsigned)g2), dim3(pb), st, x, gx, pa, D, H, W, npix);
-    else GA_LAUNCH((sga_bwd_point2<false>), dim3((unsigned)g2), dim3(pb), st, x, gx, pa, D, H, W, npix);
-    return check_launch("sga per-pixel gradients (two pixels per lane)");
-  }
   if (ndir == 4 && !accumulate && tiled) GA_LAUNCH((sga_bwd_point<4, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
@@ -767,7 +750,6 @@ GA_EXPORT int ganet_get_option(const char *name)
   if (!name) return fail(GANET_E_INVALID, "ganet_get_option: null name");
   if (!strcmp(name, "GANET_LGA_WAVE")) return g_opt.lga_wave;
   if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
-  if (!strcmp(name, "GANET_SGA_POINT2")) return g_opt.point2;
   if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
   if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
   if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
@@ -783,7 +765,6 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
   if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_POINT2")) g_opt.point2 = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);

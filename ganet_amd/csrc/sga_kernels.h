@@ -651,103 +651,6 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
   }
 }
 
-// ---- the same per-pixel kernel, TWO horizontally adjacent pixels per lane (all four directions, gradX written) ---------------
-// The one-pixel kernel issues ~5.4 M four-byte vector-memory instructions per launch at cfg2 (ten per pixel and plane), and the
-// address unit takes a wave's 64 lanes at a fixed rate whatever the width per lane: -17 % of its traffic changed nothing
-// (profiles/r7r_*), so what it is short of is not bytes.  Here a lane owns pixels (w, w + 1), w even: x, the four G and the two
-// vertical A (previous row: the same offset for both pixels) are 8-byte loads, gradX an 8-byte store; the two horizontal A keep
-// one 4-byte load per pixel (their previous positions are w - 1 / w and w + 1 / w + 2: an 8-byte load would be misaligned and,
-// at a row's end, outside the volume).  11 instead of 20 vector-memory instructions per pixel pair and plane; ONE plane of loads
-// in flight (the bytes in flight per lane of the one-pixel kernel's two), twice the per-pixel state: GA_POINT2_WAVES waves per SIMD.
-// Needs W even and 8-byte aligned volumes (launcher).  Same arithmetic per pixel, same order of sums: results identical.
-#ifndef GA_POINT2_WAVES
-#define GA_POINT2_WAVES 4
-#endif
-template <bool TG>
-__global__ void __launch_bounds__(256, GA_POINT2_WAVES)
-sga_bwd_point2(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa, int D, int H, int W, i64 npix)
-{
-  const i64 HW = (i64)H * W;
-  const i64 npair = npix >> 1;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  const int bid = GA_POINT_XCD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  for (i64 pp = (i64)bid * blockDim.x + threadIdx.x; pp < npair; pp += stride) {
-    const i64 pidx = pp << 1;
-    const i64 s = pidx / HW, pix = pidx - s * HW;
-    const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);      // w even: both pixels in row h
-    const i64 vb = s * D * HW + pix;
-    const i64 gbo = s * 5 * HW + pix;
-    i64 tb = 0;
-    if (TG) tb = (((s * (W >> 4) + (w >> 4)) * (H >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15);
-    f2 w0[4], w2[4], w3[4];
-    int poff[4][2];          // previous position in forward order per pixel (0 = none, see hpm)
-    unsigned hpm = 0;        // bit 2 q + j: direction q has a previous position at pixel j
-    f2 s0[4], s1[4], s2[4], s3[4], sg[4], mx[4];
-    f2 a_m[4], a_0[4];       // A[pp][d-1], A[pp][d]
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      w0[q] = *reinterpret_cast<const f2 *>(pa.g[q] + gbo);
-      w2[q] = *reinterpret_cast<const f2 *>(pa.g[q] + gbo + 2 * HW);
-      w3[q] = *reinterpret_cast<const f2 *>(pa.g[q] + gbo + 3 * HW);
-      // down: h-1, up: h+1, right: w-1, left: w+1 (direction q in slot q)
-      const bool hp0 = q == 0 ? h > 0 : q == 1 ? h + 1 < H : q == 2 ? w > 0 : true;
-      const bool hp1 = q == 0 ? h > 0 : q == 1 ? h + 1 < H : q == 2 ? true : w + 2 < W;
-      const int step = q == 0 ? -W : q == 1 ? W : q == 2 ? -1 : 1;
-      poff[q][0] = hp0 ? step : 0;
-      poff[q][1] = hp1 ? step : 0;
-      hpm |= (hp0 ? 1u : 0u) << (2 * q) | (hp1 ? 1u : 0u) << (2 * q + 1);
-      s0[q] = s1[q] = s2[q] = s3[q] = sg[q] = mk2(0.f, 0.f);
-      mx[q] = mk2(-INFINITY, -INFINITY);
-      a_m[q] = mk2(0.f, 0.f);
-      if (q < 2) a_0[q] = *reinterpret_cast<const f2 *>(pa.A[q] + vb + poff[q][0]);      // (vertical: one offset for both pixels)
-      else a_0[q] = mk2(pa.A[q][vb + poff[q][0]], pa.A[q][vb + 1 + poff[q][1]]);
-    }
-    for (int d = 0; d < D; d++) {
-      // every load unconditional (plane index clamped, value masked afterwards): see sga_bwd_point
-      const i64 o = vb + (i64)d * HW;
-      const i64 on = vb + (i64)(d + 1 < D ? d + 1 : D - 1) * HW;
-      const i64 ot = tb + (i64)d * 64;
-      const f2 xv = stream_load<(GA_NT_LOADS & 8) != 0>(reinterpret_cast<const f2 *>(x + o));
-      f2 Gv[4], Av[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        Gv[q] = stream_load<(GA_NT_LOADS & 2) != 0>(reinterpret_cast<const f2 *>(pa.G[q] + ((TG && q < 2) ? ot : o)));
-        if (q < 2) Av[q] = stream_load<(GA_NT_LOADS & 2) != 0>(reinterpret_cast<const f2 *>(pa.A[q] + on + poff[q][0]));
-        else Av[q] = mk2(stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + on + poff[q][0]),
-                         stream_load<(GA_NT_LOADS & 2) != 0>(pa.A[q] + on + 1 + poff[q][1]));      // A[pp][d+1] (used only where d + 1 < D)
-      }
-      f2 gacc = mk2(0.f, 0.f);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const f2 G_ = Gv[q], a_p = Av[q];
-        f2 r = mk2(G_.x * w0[q].x, G_.y * w0[q].y);
-        if (d == 0) r = mk2(fmaf(G_.x, w2[q].x, r.x), fmaf(G_.y, w2[q].y, r.y));
-        if (d == D - 1) r = mk2(fmaf(G_.x, w3[q].x, r.x), fmaf(G_.y, w3[q].y, r.y));
-        gacc = mk2(gacc.x + r.x, gacc.y + r.y);
-        s0[q] = fma2(G_, xv, s0[q]);
-        sg[q] = add2(sg[q], G_);
-        s1[q] = fma2(G_, a_0[q], s1[q]);
-        s2[q] = fma2(G_, d >= 1 ? a_m[q] : xv, s2[q]);
-        s3[q] = fma2(G_, d + 1 < D ? a_p : xv, s3[q]);
-        mx[q] = mk2(fmaxf(mx[q].x, a_0[q].x), fmaxf(mx[q].y, a_0[q].y));
-        a_m[q] = a_0[q];
-        a_0[q] = a_p;
-      }
-      stream_store<(GA_NT_STORES & 8) != 0>(reinterpret_cast<f2 *>(gradX + o), gacc);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      float *gw = pa.gw[q] + gbo;
-      const bool hp0 = (hpm >> (2 * q)) & 1u, hp1 = (hpm >> (2 * q + 1)) & 1u;
-      *reinterpret_cast<f2 *>(gw) = s0[q];
-      *reinterpret_cast<f2 *>(gw + HW) = mk2(hp0 ? s1[q].x : 0.f, hp1 ? s1[q].y : 0.f);
-      *reinterpret_cast<f2 *>(gw + 2 * HW) = mk2(hp0 ? s2[q].x : 0.f, hp1 ? s2[q].y : 0.f);
-      *reinterpret_cast<f2 *>(gw + 3 * HW) = mk2(hp0 ? s3[q].x : 0.f, hp1 ? s3[q].y : 0.f);
-      *reinterpret_cast<f2 *>(gw + 4 * HW) = mk2(hp0 ? sg[q].x * mx[q].x : 0.f, hp1 ? sg[q].y * mx[q].y : 0.f);
-    }
-  }
-}
-
 // ---- direction merge + arg-max, one lane per pixel --------------------------------------------
 // out = A0; mask = 0; for dir 1..3: if (out < A_dir) { out = A_dir; mask = dir; }
 // (Max, GANet_kernel.cu:23-36, fused over the 4 volumes) and, in the same sweep,

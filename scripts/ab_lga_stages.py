@@ -15,7 +15,6 @@ for rep in range(2):
             if libname not in DEFAULTS:
                 DEFAULTS[libname] = _native._LIB.get_option("GANET_SGA_TILED")
             _native._LIB.set_option("GANET_SGA_TILED", DEFAULTS[libname])
-            _native._LIB.set_option("GANET_SGA_POINT2", 0)
         except Exception:
             pass
         for kv in filter(None, optstr.split(",")):

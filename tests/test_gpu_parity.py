@@ -187,20 +187,6 @@ def test_sga_tiled_private_workspace(api, dev, port_oracle, shape, tiled):
         api.set_option("GANET_SGA_TILED", was)
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 65, 80, 208), (1, 4, 33, 8, 48), (2, 3, 48, 12, 80), (1, 2, 9, 3, 4)])
-def test_sga_per_pixel_kernel_two_pixels_per_lane(api, dev, port_oracle, shape):
-    """GANET_SGA_POINT2 (sga_kernels.h: sga_bwd_point2): two horizontally adjacent pixels per lane in the per-pixel gradient
-    kernel; same gradients within 1e-4 of the oracle at the full cfg2 size and at small sizes whose rows end inside a lane pair."""
-    was = api.get_option("GANET_SGA_POINT2")
-    api.set_option("GANET_SGA_POINT2", 1)
-    try:
-        x, gs, go = pc.sga_inputs(shape, seed=17)
-        err = pc.check_sga_forward_backward(api, dev, x, gs, go, _oracle_want(port_oracle, x, gs, go))
-        assert max(err.values()) <= pc.TOL, err
-    finally:
-        api.set_option("GANET_SGA_POINT2", was)
-
-
 def test_full_size_properties(api, dev):
     """Size-independent properties at the full cfg2 shapes (no oracle involved):
     SGA is positively homogeneous -- scaling x by 2 scales every volume by exactly 2 and leaves

@@ -199,21 +199,3 @@ def test_tiled_workspace_falls_back_where_it_does_not_apply(sim, port_oracle):
             assert max(err.values()) < 2e-5, err
     finally:
         sim.set_option("GANET_SGA_TILED", was)
-
-
-@pytest.mark.parametrize("tiled", [0, 1])
-@pytest.mark.parametrize("shape", [(1, 2, 33, 8, 32), (1, 1, 65, 4, 48), (2, 1, 9, 12, 16), (1, 2, 6, 3, 4), (1, 1, 20, 2, 20)])
-def test_per_pixel_kernel_two_pixels_per_lane(sim, port_oracle, shape, tiled):
-    """GANET_SGA_POINT2: sga_bwd_point2 (a lane owns pixels (w, w + 1): 8-byte loads of x / G / the vertical A, one 4-byte load per
-    pixel for the horizontal A, whose previous positions at the row ends would leave the volume).  Same gradients, with the
-    vertical adjoint volumes tiled and not; shapes with rows of 4 .. 48 pixels (every lane pair touches a row end at W = 4)."""
-    was_t, was_p = sim.get_option("GANET_SGA_TILED"), sim.get_option("GANET_SGA_POINT2")
-    sim.set_option("GANET_SGA_TILED", tiled)
-    sim.set_option("GANET_SGA_POINT2", 1)
-    try:
-        x, gs, go = pc.sga_inputs(shape, seed=sum(shape) + 11 * tiled)
-        err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
-        assert max(err.values()) < 2e-5, err
-    finally:
-        sim.set_option("GANET_SGA_TILED", was_t)
-        sim.set_option("GANET_SGA_POINT2", was_p)
