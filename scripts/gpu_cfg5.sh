@@ -7,6 +7,9 @@
 # Winograd kernels), MIOpen's user db + kernel cache are copied to gpurun_out/ once a minute, and the step is killed hard.
 TAG=${1:-r7h}
 BUDGET=${2:-780}
+MODE=${3:-find}      # find: MIOpen find mode (times the applicable solvers per problem); immediate: PyTorch's default mode, where MIOpen
+                     # takes the first applicable solver -- with the naive / GEMM / FFT families disabled below that is a CK implicit-GEMM,
+                     # Winograd or direct-asm kernel, one compilation per problem and no benchmarking
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -23,7 +26,8 @@ export MIOPEN_ENABLE_LOGGING_CMD=1
   done ) &
 COPIER=$!
 SECONDS=0
-timeout -k 5 -s INT $BUDGET python -m harness.train --crop_height 528 --crop_width 960 --batch 2 --steps 2 --warmup 1 --fused > $OUT/cfg5_train.json 2> $OUT/cfg5_train.err
+EXTRA=""; [ "$MODE" = "immediate" ] && EXTRA="--no_miopen_find"
+timeout -k 5 -s INT $BUDGET python -m harness.train --crop_height 528 --crop_width 960 --batch 2 --steps 2 --warmup 1 --fused $EXTRA > $OUT/cfg5_train.json 2> $OUT/cfg5_train.err
 echo "cfg5 rc=$? (${SECONDS}s)"; cut -c1-600 $OUT/cfg5_train.json
 kill $COPIER 2>/dev/null
 grep -c "MIOpenDriver" $OUT/cfg5_train.err; grep "MIOpenDriver" $OUT/cfg5_train.err | sort -u | wc -l
