@@ -17,10 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from harness.miopen_env import disable_slow_solver_families, use_repo_miopen_cache  # noqa: E402
+from harness.miopen_env import use_repo_miopen_cache  # noqa: E402
 
 use_repo_miopen_cache()            # before torch loads MIOpen
-disable_slow_solver_families()
 
 import torch  # noqa: E402
 
@@ -35,12 +34,8 @@ def main():
     ap.add_argument("--max_disp", type=int, default=192)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--fused", action="store_true", help="ganet_amd.modules.fused op chains instead of the stock call forms")
-    ap.add_argument("--miopen_find", dest="miopen_find", action="store_true",
-                    help="MIOpen find mode: time the applicable solvers once per convolution problem (minutes for a new set of "
-                         "training shapes).  Default: immediate mode with the naive / GEMM / FFT solver families off "
-                         "(harness/miopen_env.py): as fast at cfg4, no search")
-    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false", help=argparse.SUPPRESS)      # (the default since round 4)
-    ap.set_defaults(miopen_find=False)
+    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
+                    help="MIOpen immediate mode (heuristic solver choice) instead of timing its solvers per shape")
     ap.add_argument("--kernel_share", action="store_true", help="add the per-group device-time table (torch.profiler over 2 extra passes)")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -78,7 +73,7 @@ def main():
         "ops": "ganet_amd.modules.fused (%d call sites)" % n_fused if args.fused else "drop-in call forms (libs/)",
         "ms_per_pair": round(times[len(times) // 2], 3), "ms_min": round(times[0], 3), "iters": args.iters,
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
-        "miopen_find": bool(args.miopen_find), "miopen_slow_families_off": os.environ.get("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD") == "0", "params": sum(p.numel() for p in model.parameters()), "dtype": "f32", "weights": "random init",
+        "miopen_find": bool(args.miopen_find), "params": sum(p.numel() for p in model.parameters()), "dtype": "f32", "weights": "random init",
         "disp_range": [round(float(out.min()), 3), round(float(out.max()), 3)],
         "device": torch.cuda.get_device_name(0), "kernel_share": share}))
 

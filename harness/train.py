@@ -19,10 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from harness.miopen_env import disable_slow_solver_families, use_repo_miopen_cache  # noqa: E402
+from harness.miopen_env import use_repo_miopen_cache  # noqa: E402
 
 use_repo_miopen_cache()            # before torch loads MIOpen
-disable_slow_solver_families()
 
 import torch  # noqa: E402
 
@@ -43,12 +42,8 @@ def parse(argv=None):
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--kitti", type=int, default=1)
     ap.add_argument("--sync_bn", action="store_true")
-    ap.add_argument("--miopen_find", dest="miopen_find", action="store_true",
-                    help="MIOpen find mode: time the applicable solvers once per convolution problem (minutes for a new set of "
-                         "training shapes).  Default: immediate mode with the naive / GEMM / FFT solver families off "
-                         "(harness/miopen_env.py): as fast at cfg4, no search")
-    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false", help=argparse.SUPPRESS)      # (the default since round 4)
-    ap.set_defaults(miopen_find=False)
+    ap.add_argument("--no_miopen_find", dest="miopen_find", action="store_false",
+                    help="MIOpen immediate mode (heuristic solver choice) instead of timing its solvers per shape")
     ap.add_argument("--fused", action="store_true")
     ap.add_argument("--kernel_share", action="store_true", help="add the per-group device-time table (torch.profiler over 2 extra steps, rank 0)")
     ap.add_argument("--resume", default="")
@@ -104,7 +99,7 @@ def run(args, hook=None):
             "per_gpu_batch": args.batch, "crop": [args.crop_height, args.crop_width], "max_disp": args.max_disp,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "samples_per_sec": round(ctx.world_size * args.batch * args.steps / elapsed, 3),
-            "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find), "miopen_slow_families_off": os.environ.get("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD") == "0", "sync_bn": bool(args.sync_bn and ctx.world_size > 1),
+            "steps": args.steps, "warmup": args.warmup, "miopen_find": bool(args.miopen_find), "sync_bn": bool(args.sync_bn and ctx.world_size > 1),
             "ops": "ganet_amd.modules.fused" if args.fused else "drop-in call forms (libs/)",
             "grad_allreduce": "DistributedDataParallel (RCCL)" if ctx.world_size > 1 and not cpu else
                               ("DistributedDataParallel (gloo)" if ctx.world_size > 1 else "none (1 rank)"),
