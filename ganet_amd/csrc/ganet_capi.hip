@@ -557,10 +557,6 @@ LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items)
   return mx;
 }
 
-#ifndef GA_FG_LA
-#define GA_FG_LA 0          // window rows of LDS look-ahead in the plane-pair filter gradient (radius 2): 0 or 1 are spill-free at
-                            // three waves per SIMD (scripts/isa_loop_check.py); the launch sites below use this value
-#endif
 #ifndef GA_LGA_PLANAR
 #define GA_LGA_PLANAR 1     // API-layout operands of the plane-pair kernels staged planar by 16-byte copies where W % 4 == 0
 #endif
@@ -633,9 +629,9 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, GA_FG_LA>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, GA_FG_LA>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, GA_FG_LA>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
 }
 
@@ -682,7 +678,7 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
         bool planar = false;
         if constexpr (R == 2) {
           planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
-          if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, GA_FG_LA>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+          if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         }
         if (!planar) GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         return check_launch("lga filter grad (plane pairs)");

@@ -123,3 +123,31 @@ def test_reference_models_import_on_top_of_the_drop_in(monkeypatch):
     assert sum(p.numel() for p in net.parameters()) == 6580112
     import ganet_amd.modules.GANet as M
     assert isinstance(net.cost_agg.sga1.SGA, M.SGA)
+
+
+def test_bench_roofline_object_from_stage_times():
+    """bench.roofline_from_stages on the stage names bench.stage_timings produces (no GPU): every family row is built from the
+    kernels' own times (no difference of other measurements), LGA families carry the fp32 bound, the line states the MFMA answer
+    and the measured-achievable peaks, and the per-kernel traffic lookup accepts the alternative names of one kernel."""
+    sys.path.insert(0, ROOT)
+    import bench
+    st = {"sga_scan_fwd_down": 0.07, "sga_scan_fwd_up": 0.07, "sga_scan_fwd_right": 0.07, "sga_scan_fwd_left": 0.07,
+          "sga_merge_argmax": 0.11, "sga_bwd_scan_down": 0.08, "sga_bwd_scan_up": 0.08, "sga_bwd_scan_right": 0.07,
+          "sga_bwd_scan_left": 0.07, "sga_bwd_point": 0.29, "lga_fwd_pass": 0.09, "lga_bwd_pass": 0.19}
+    r = bench.roofline_from_stages(st)
+    fam = {f["kernel"]: f for f in r["families"]}
+    assert set(fam) == {"sga_scan_fwd", "sga_merge_argmax", "sga_bwd_scan", "sga_bwd_point",
+                        "lga_apply+filter_grad (bwd pass)", "lga_apply (fwd pass)"}
+    assert fam["sga_merge_argmax"]["avg_launch_ms"] == 0.11 and fam["sga_bwd_point"]["avg_launch_ms"] == 0.29
+    assert abs(fam["sga_scan_fwd"]["step_ms"] - 0.28) < 1e-9 and fam["sga_scan_fwd"]["launches_per_step"] == 4
+    assert fam["lga_apply (fwd pass)"]["bound"] == "fp32" and fam["sga_bwd_point"]["bound"] == "hbm"
+    # dominant family = largest share of the step; its fraction against its binding bound
+    assert r["kernel"] == "lga_apply+filter_grad (bwd pass)" and r["bound"].startswith("fp32")
+    assert abs(r["frac"] - 2 * bench._LGA_PASS_FLOPS / 0.19e-3 / 1e12 / bench.FP32_PEAK_TFLOPS) < 1e-3
+    assert r["mfma"]["used"] is False and r["mfma"]["mfma_utilisation"] == 0.0
+    assert r["achievable"]["hbm_copy_GBs"] < bench.HBM_PEAK_GBS and r["achievable"]["fp32_pk_fma_TFLOPs"] < bench.FP32_PEAK_TFLOPS
+    kern = {"sga_bwd_point<4, false>": {"read_bytes": 10, "write_bytes": 5}}
+    assert bench._family_traffic("sga_bwd_point", kern) == 15
+    kern = {"sga_bwd_point<4, false, true>": {"read_bytes": 7, "write_bytes": 1}, "sga_bwd_point<4, false>": {"read_bytes": 10, "write_bytes": 5}}
+    assert bench._family_traffic("sga_bwd_point", kern) == 8
+    assert bench._family_traffic("sga_merge_argmax", kern) is None
