@@ -131,8 +131,12 @@ def _planar_chain(sim, port_oracle, shape, paired):
     return chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
 
 
-@pytest.mark.parametrize("paired", [0, 1])
-def test_lga_planar_reads_with_late_landing_lds(sim, port_oracle, paired):
+@pytest.mark.parametrize("paired,segs,mix", [(0, 0, 1), (1, 0, 1), (0, 2, 0), (1, 3, 0), (1, 0, 2)])
+def test_lga_planar_reads_with_late_landing_lds(sim, port_oracle, paired, segs, mix):
+    """(segs / mix: whole tiles, every tile cut into depth segments, the mixed item list -- a segment starts and ends its ring,
+    its row look-ahead and its counted waits somewhere inside the volume)"""
+    sim.set_option("GANET_LGA_SEGS", segs)
+    sim.set_option("GANET_LGA_MIX", mix)
     sim.set_option("HIPSIM_LATE_LDS", 1)
     sim.set_option("HIPSIM_LATE_DMA", 1)
     try:
@@ -142,6 +146,8 @@ def test_lga_planar_reads_with_late_landing_lds(sim, port_oracle, paired):
     finally:
         sim.set_option("HIPSIM_LATE_LDS", 0)
         sim.set_option("HIPSIM_LATE_DMA", 0)
+        sim.set_option("GANET_LGA_SEGS", 0)
+        sim.set_option("GANET_LGA_MIX", 1)
 
 
 @pytest.mark.parametrize("which,slack", [("HIPSIM_LGKM_SLACK", 1), ("HIPSIM_VMCNT_SLACK", 1)])

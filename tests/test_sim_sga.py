@@ -199,3 +199,22 @@ def test_tiled_workspace_falls_back_where_it_does_not_apply(sim, port_oracle):
             assert max(err.values()) < 2e-5, err
     finally:
         sim.set_option("GANET_SGA_TILED", was)
+
+
+def test_tiled_workspace_random_shapes(sim, port_oracle):
+    """Seeded random shapes with W % 16 == 0 and H % 4 == 0 (one to four column blocks, one to four row batches, depths from one
+    lane's worth to several, one to three slices): the tiled adjoint workspace against the oracle and against its own API-layout
+    twin (parity_cases.check_sga_forward_backward does both)."""
+    rng = np.random.default_rng(20260925)
+    was = sim.get_option("GANET_SGA_TILED")
+    sim.set_option("GANET_SGA_TILED", 1)
+    try:
+        for _ in range(6):
+            shape = (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(2, 40)), 4 * int(rng.integers(1, 5)), 16 * int(rng.integers(1, 5)))
+            N, C, D, H, W = shape
+            assert sim.query("ganet_sga_workspace_layout", N, C, D, H, W) == 1
+            x, gs, go = pc.sga_inputs(shape, seed=int(rng.integers(1 << 30)))
+            err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
+            assert max(err.values()) < 3e-5, (shape, err)
+    finally:
+        sim.set_option("GANET_SGA_TILED", was)
