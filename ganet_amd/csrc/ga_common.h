@@ -157,6 +157,13 @@ GA_DEV int lane_id()
 #endif
 }
 
+// a value the program knows to be the same in every lane of the wavefront, told to the compiler (v_readfirstlane -> an SGPR)
+#if defined(GA_HIPSIM)
+#define GA_UNIFORM_I(v) (v)
+#else
+#define GA_UNIFORM_I(v) __builtin_amdgcn_readfirstlane(v)
+#endif
+
 // Workgroup barrier for hand-offs that go through LDS only.  __syncthreads() is a fence + barrier, and
 // the fence drains the vector-memory counter as well: every global load still in flight (the prefetch
 // of the next tile) and every result store is waited for at each barrier.  Here only the LDS queue
@@ -169,7 +176,7 @@ GA_DEV int lane_id()
 
 // hand-off between the lanes of ONE wavefront through LDS (kernels whose workgroup is a single wave)
 #if defined(GA_HIPSIM)
-#define GA_WAVE_SYNC() __syncthreads()     // emulator: the block IS one wave in these kernels
+#define GA_WAVE_SYNC() hipsim::wave_sync()     // emulator: a barrier over the caller's own wavefront
 #else
 // no instruction: the lanes of a wave run in lockstep and its LDS queue is in order; this only
 // stops the compiler from moving LDS accesses across the hand-off

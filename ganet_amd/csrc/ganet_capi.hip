@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
+  std::atomic<int> lga_wg{0};       // plane-pair forward / data-backward of API-layout volumes: ONE ring per 256-thread workgroup on 32 x 8 tiles (lga_apply_pp_wx / _wxo) instead of one per wave; built and emulator-verified in round 4, not yet measured: off
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -85,6 +86,7 @@ void load_env_options()
   geti("GANET_SGA_TILED", g_opt.sga_tiled);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
+  geti("GANET_LGA_WG", g_opt.lga_wg);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
@@ -516,18 +518,20 @@ int device_cus()
 // (profiles/r2f_lga_pp_ablation.txt), so whole tiles are best (profiles/r2e_ab_lga_plane_pairs_v2.txt) unless there are too few
 // of them to fill the wave slots; with a whole number q < 3 of tiles per SIMD plus a remainder, the remainder is cut into
 // segments, at most one per SIMD (the mixed list).  `whole_only`: the pass carries a per-pixel reduction over all of D.
-LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items)
+// `wg`: items of the workgroup kernels (32 x 8 tiles, four waves each: the unit that takes an item is a CU, not a SIMD).
+LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items, bool wg = false)
 {
   LgaSegMix mx;
+  const int th = wg ? 8 : LGAW_TH, units = (wg ? 1 : 4) * device_cus();
   mx.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-  mx.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+  mx.tiles_y = (H + th - 1) / th;
   const i64 tiles = (i64)mx.tiles_x * mx.tiles_y * B;
   mx.n_whole = (int)(tiles < (1ll << 30) ? tiles : (1ll << 30));
   mx.nsub = 1;
   mx.sub_len = (D + 1) & ~1;
   *items = tiles;
   if (whole_only || tiles >= (1ll << 30)) return mx;
-  const i64 slots = (i64)LGA_WAVES_PER_SIMD * 4 * device_cus();
+  const i64 slots = (i64)LGA_WAVES_PER_SIMD * units;
   int nseg = opts().lga_segs;
   if (nseg <= 0) {
     nseg = tiles * 2 > slots ? 1 : (int)((slots + tiles - 1) / tiles);
@@ -542,7 +546,7 @@ LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items)
     return mx;
   }
   const int mixo = opts().lga_mix;
-  const i64 S = mixo > 1 ? (i64)mixo : (i64)4 * device_cus();
+  const i64 S = mixo > 1 ? (i64)mixo : (i64)units;
   if (mixo && opts().lga_segs <= 0 && tiles / S < LGA_WAVES_PER_SIMD && tiles % S != 0) {
     const i64 r = tiles % S;
     int nsub = (int)(S / r);
@@ -569,10 +573,20 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   if constexpr (R <= 2) {
     if (opts().lga_wave && (i64)H * W < (1ll << 28)) {
       i64 items;
+      bool planar = false;
+      if constexpr (R == 2) planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);      // input staged by 16-byte copies
+      if constexpr (R == 2) {
+        if (planar && opts().lga_wg) {                      // one ring per 256-thread workgroup (32 x 8 tiles)
+          const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
+          if (items < (1ll << 31)) {
+            if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            else GA_LAUNCH((lga_apply_pp_wx<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            return check_launch("lga apply (plane pairs, workgroup ring)");
+          }
+        }
+      }
       const LgaSegMix mx = lga_items(W, H, B, D, false, &items);
       if (items < (1ll << 31)) {
-        bool planar = false;
-        if constexpr (R == 2) planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);      // input staged by 16-byte copies
         if constexpr (R == 2) {
           if (planar && transposed) GA_LAUNCH((lga_apply_pp_x<2, true>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
           else if (planar) GA_LAUNCH((lga_apply_pp_x<2, false>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, mx);
@@ -601,9 +615,17 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   i64 items;
+  float *const none = nullptr;
+  if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // one ring per 256-thread workgroup (32 x 8 tiles)
+    const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
+    if (items < (1ll << 31)) {
+      if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else GA_LAUNCH((lga_apply_pp_wxo<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      return check_launch("lga apply (plane pairs, interleaved volume, workgroup ring)");
+    }
+  }
   const LgaSegMix sg = lga_items(W, H, B, D, false, &items);
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_apply_paired: too many tiles");
-  float *const none = nullptr;
 #define L(K, T) GA_LAUNCH((K<2, T>), dim3((unsigned)items), dim3(64), st, x, f, y, geo, sg, none, none, edge)
   if (x_paired) {
     if (transposed) L(lga_apply_pp_pi, true); else L(lga_apply_pp_pi, false);
@@ -747,6 +769,7 @@ GA_EXPORT int ganet_get_option(const char *name)
   if (!strcmp(name, "GANET_LGA_WAVE")) return g_opt.lga_wave;
   if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
   if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
+  if (!strcmp(name, "GANET_LGA_WG")) return g_opt.lga_wg;
   if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
   if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
   if (!strcmp(name, "GANET_SGA_WIDE_COL")) return g_opt.wide_col;
@@ -763,6 +786,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
+  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;

@@ -390,6 +390,9 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_NR
 #define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
 #endif
+#ifndef LGAP_WG_NR
+#define LGAP_WG_NR 8      // ring slots (4 KB each) of the workgroup-shared ring: 34 KB per workgroup, three workgroups per CU (see the march of lga_apply_pp.inc)
+#endif
 #ifndef LGAP_ROW_ASM
 #define LGAP_ROW_ASM 1           // radius 2: a window row's 15 packed FMAs as one asm statement (lga_row_fma); 0 = one statement per FMA
 #endif
@@ -734,6 +737,22 @@ GA_DEV void lga_dma16p_pair(const float *base, const unsigned (&o)[2], float *sl
 #endif
 }
 
+// ONE 16-byte copy per lane: lane l's 16 bytes from base + off to slot + 16 l (the workgroup-shared ring of lga_apply_pp.inc,
+// GA_PP_IN = 3: `slot` is this wave's quarter of the ring slot)
+GA_DEV void lga_dma16p_one(const float *base, unsigned off, float *slot, int lane)
+{
+#if defined(GA_HIPSIM)
+  hipsim::dma_issue(slot + 4 * lane, reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off), 4);
+#else
+  (void)lane;
+  __builtin_assume(slot != nullptr);
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
+  unsigned keep;
+  asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2 offset:0\n\t" GA_M0_RESTORE_TAIL
+               : "=&s"(keep) : "s"(dst), "s"(base), "v"(off) : "memory", "scc");
+#endif
+}
+
 // ---- item list of the forward / data-backward kernels: whole tiles first, then tiles cut into depth segments -----------------
 // These kernels are bound by VALU issue and the waves of a SIMD share one VALU, so a pass lasts as long as the SIMD with the
 // most resident work: 2,400 tiles on 1,024 SIMDs are 2 or 3 tiles per SIMD and the pass takes the time of 3 (the FMA-only
@@ -804,6 +823,25 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #undef GA_PP_NDC
 #undef GA_PP_Y
 
+// API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WG)
+#define GA_PP_NAME lga_apply_pp_wx
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 3
+#define GA_PP_OUT 0
+#define GA_PP_SLOT 1024
+#define GA_PP_NDC 1
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+
 #define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
 // API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
 #define GA_PP_NAME lga_apply_pp_po
@@ -831,6 +869,24 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_OUT 1
 #define GA_PP_SLOT 512
 #define GA_PP_NDC 2
+#define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+// the same with ONE planar ring per 256-thread workgroup (GANET_LGA_WG)
+#define GA_PP_NAME lga_apply_pp_wxo
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 3
+#define GA_PP_OUT 1
+#define GA_PP_SLOT 1024
+#define GA_PP_NDC 1
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
 #undef GA_PP_NAME

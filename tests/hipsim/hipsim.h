@@ -121,6 +121,15 @@ inline void barrier_wait(Barrier &b, int n)
 inline int flat_tid() { State &s = S(); const dim3 &t = s.fibers[s.cur].tidx; return t.x + s.blockDim_.x * (t.y + s.blockDim_.y * t.z); }
 inline int lane_id() { return flat_tid() & 63; }
 inline void syncthreads() { State &s = S(); barrier_wait(s.block_bar, s.nthreads); }
+// hand-off between the lanes of ONE wavefront (GA_WAVE_SYNC): a barrier over the caller's 64 threads only -- in a workgroup of
+// several waves it must not synchronise the others, or a missing workgroup barrier would go unnoticed here
+inline void wave_sync()
+{
+  State &s = S();
+  const int wave = flat_tid() >> 6;
+  const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
+  barrier_wait(s.wave_bar[wave], wsize);
+}
 
 inline void dma_land(const State::DmaOp &op) { for (int k = 0; k < op.n; k++) op.dst[k] = op.v[k]; }
 // one lane's share of a global -> LDS copy instruction: n floats from src to dst (n == 0: the lane is masked out of the

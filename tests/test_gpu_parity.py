@@ -534,3 +534,47 @@ def test_cost_volume_and_regression_cfg3_cfg5_sizes(api, dev, port_oracle, N, C,
     gp = dev.empty(p.shape)
     api.call("ganet_disparity_regression_backward", dev.to(go).data_ptr(), gp.data_ptr(), N, Dr, Hr, Wr, dev.stream)
     assert np.array_equal(dev.host(gp), go[:, None] * np.arange(Dr, dtype=np.float32)[None, :, None, None])
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 240, 624), (1, 33, 7, 36), (2, 9, 3, 64), (1, 5, 66, 132), (1, 64, 13, 100), (1, 2, 2, 4),
+                                   (1, 21, 61, 96)])
+@pytest.mark.parametrize("paired", [0, 1])
+def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape, paired):
+    """GANET_LGA_WG=1: the forward / data-backward of API-layout volumes with one LDS ring per 256-thread workgroup (32 x 8
+    tiles; lga_apply_pp_wx / _wxo).  Same arithmetic per pixel as the one-wave kernels, in the same order: results must be
+    BIT-identical to theirs on whole tiles (segments cut the depth axis per tile count, which differs), reproducible over
+    repeated runs (the hand-off between the four waves is one counted wait + one barrier per plane pair), and agree with the
+    oracle; then once more with the item lists each form chooses for itself."""
+    torch = dev.torch
+    B, D, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(shape, device="cuda", generator=g)
+    f = torch.nn.functional.normalize(torch.randn((B, 75, H, W), device="cuda", generator=g), p=1, dim=1)
+    gy = torch.randn(shape, device="cuda", generator=g)
+    xn, fn, gyn = x.cpu().numpy(), f.cpu().numpy(), gy.cpu().numpy()
+    want = None
+    if x.numel() <= 4_000_000:
+        y, ins = port_oracle.lga_chain_forward(xn, fn, 2, 2)
+        ogx, ogf = port_oracle.lga_chain_backward(ins, fn, gyn, 2)
+        want = {"y": y, "gx": ogx, "gf": ogf}
+    chain = pc.check_lga2_paired if paired else pc.check_lga_chain
+    res = {}
+    try:
+        for mix, segs in ((0, 1), (1, 0)):
+            api.set_option("GANET_LGA_MIX", mix)
+            api.set_option("GANET_LGA_SEGS", segs)
+            for wg in (0, 1, 1):
+                api.set_option("GANET_LGA_WG", wg)
+                got = {}
+                chain(api, dev, xn, fn, gyn, 2, 2, want, out=got)
+                if (mix, wg) in res:
+                    assert all(np.array_equal(got[k], res[mix, wg][k]) for k in got), "workgroup ring: not reproducible"
+                res[mix, wg] = got
+                dev.release()
+    finally:
+        api.set_option("GANET_LGA_WG", 0)
+        api.set_option("GANET_LGA_MIX", 1)
+        api.set_option("GANET_LGA_SEGS", 0)
+    for k in res[0, 0]:
+        assert np.array_equal(res[0, 0][k], res[0, 1][k]), (k, float(np.abs(res[0, 0][k] - res[0, 1][k]).max()))
+        assert np.abs(res[1, 0][k] - res[1, 1][k]).max() <= pc.TOL, k

@@ -211,3 +211,103 @@ def test_lga_families_with_reversed_thread_order(sim, port_oracle, reversed_lane
 def test_sga_with_reversed_thread_order(sim, port_oracle, reversed_lanes, shape):
     x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
     pc.check_sga_forward_backward(sim, pc.NumpyDev(), x, gs, go, _sga_want(port_oracle, x, gs, go))
+
+
+# ---- the workgroup-shared ring (GANET_LGA_WG=1: lga_apply_pp_wx / _wxo, four waves on a 32 x 8 tile) ------------------------
+# What is new against the one-wave kernels is a hand-off BETWEEN waves: every wave stages a quarter of each ring slot, waits for
+# its own copies (counted) and meets the others at one workgroup barrier per pair-step.  The emulator's wave barrier covers the
+# caller's wavefront only, its copies land as late as the issuing lane's own waits allow, and threads between two barriers run
+# one after the other: a missing or misplaced workgroup barrier reads a slot quarter another wave has not even requested.
+_WG_SHAPES = [(1, D, 11, 36) for D in (1, 2, 3, 8, 9, 13, 14, 21, 26, 27)] + \
+             [(2, 13, 5, 68), (1, 22, 2, 8), (1, 15, 9, 40), (1, 33, 1, 4), (1, 12, 8, 32), (1, 10, 17, 64), (1, 7, 16, 4), (1, 40, 9, 36),
+              (1, 41, 3, 36)]
+
+
+@pytest.fixture()
+def wg_ring(sim):
+    sim.set_option("GANET_LGA_WG", 1)
+    yield
+    sim.set_option("GANET_LGA_WG", 0)
+
+
+@pytest.mark.parametrize("guard", ["end", "start"])
+@pytest.mark.parametrize("paired,segs,mix", [(0, 0, 1), (1, 0, 1), (0, 2, 0), (1, 3, 0), (1, 0, 2), (0, 0, 3)])
+def test_lga_workgroup_ring_late_landing_guarded(sim, port_oracle, wg_ring, paired, segs, mix, guard):
+    sim.set_option("GANET_LGA_SEGS", segs)
+    sim.set_option("GANET_LGA_MIX", mix)
+    sim.set_option("HIPSIM_LATE_LDS", 1)
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        for shape in _WG_SHAPES:
+            dev = pc.NumpyDev(guard)
+            rng = np.random.default_rng(sum(shape))
+            B, D, H, W = shape
+            x = rng.standard_normal(shape).astype(np.float32)
+            f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+            gy = rng.standard_normal(shape).astype(np.float32)
+            y, ins = port_oracle.lga_chain_forward(x, f, 2, 2)
+            gx, gf = port_oracle.lga_chain_backward(ins, f, gy, 2)
+            chain = pc.check_lga2_paired if paired else pc.check_lga_chain
+            err = chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
+            assert max(err.values()) < 5e-5, (shape, err)
+    finally:
+        sim.set_option("HIPSIM_LATE_LDS", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+        sim.set_option("GANET_LGA_SEGS", 0)
+        sim.set_option("GANET_LGA_MIX", 1)
+
+
+def test_lga_workgroup_ring_is_what_runs(sim, wg_ring):
+    """the option reaches the launcher (a test of the one-wave kernels under another name would prove nothing)"""
+    assert sim.get_option("GANET_LGA_WG") == 1
+
+
+@pytest.mark.parametrize("paired", [0, 1])
+def test_lga_workgroup_ring_reversed_thread_order(sim, port_oracle, wg_ring, reversed_lanes, paired):
+    for shape in [(1, 9, 11, 36), (2, 21, 5, 68), (1, 14, 9, 40), (1, 26, 16, 32)]:
+        err = _planar_chain(sim, port_oracle, shape, paired)
+        assert max(err.values()) < 5e-5, (shape, err)
+
+
+def test_lga_workgroup_ring_loosened_wait_fails(sim, port_oracle, wg_ring):
+    """one copy too many left in flight at the per-step wait: the barrier then publishes a slot quarter that has not landed"""
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    sim.set_option("HIPSIM_VMCNT_SLACK", 1)
+    try:
+        bad = 0
+        for shape in [(1, 13, 11, 36), (1, 26, 8, 36), (2, 13, 5, 68)]:
+            try:
+                err = _planar_chain(sim, port_oracle, shape, 1)
+                bad += not (max(err.values()) < 5e-5)
+            except AssertionError:
+                bad += 1
+        assert bad > 0, "HIPSIM_VMCNT_SLACK=1 went unnoticed by the workgroup ring"
+    finally:
+        sim.set_option("HIPSIM_VMCNT_SLACK", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
+
+
+@pytest.mark.parametrize("paired", [0, 1])
+def test_lga_workgroup_ring_bit_identical_to_one_wave_kernels(sim, port_oracle, paired):
+    """same arithmetic per pixel in the same order: on whole tiles the two forms agree bit for bit"""
+    sim.set_option("GANET_LGA_MIX", 0)
+    sim.set_option("GANET_LGA_SEGS", 1)
+    try:
+        for shape in [(1, 13, 11, 36), (2, 8, 5, 68), (1, 27, 16, 32)]:
+            rng = np.random.default_rng(sum(shape))
+            B, D, H, W = shape
+            x = rng.standard_normal(shape).astype(np.float32)
+            f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+            gy = rng.standard_normal(shape).astype(np.float32)
+            res = []
+            for wg in (0, 1):
+                sim.set_option("GANET_LGA_WG", wg)
+                got = {}
+                (pc.check_lga2_paired if paired else pc.check_lga_chain)(sim, pc.NumpyDev(), x, f, gy, 2, 2, None, out=got)
+                res.append(got)
+            for k in res[0]:
+                assert np.array_equal(res[0][k], res[1][k]), (shape, k)
+    finally:
+        sim.set_option("GANET_LGA_WG", 0)
+        sim.set_option("GANET_LGA_MIX", 1)
+        sim.set_option("GANET_LGA_SEGS", 0)
