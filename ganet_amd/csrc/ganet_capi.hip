@@ -65,7 +65,7 @@ struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
-  std::atomic<int> lga_wg{0};       // plane-pair forward / data-backward of API-layout volumes: ONE ring per 256-thread workgroup on 32 x 8 tiles (lga_apply_pp_wx / _wxo) instead of one per wave; built and emulator-verified in round 4, not yet measured: off
+  std::atomic<int> lga_wg{0};       // plane-pair forward / data-backward of API-layout volumes: ONE ring per 256-thread workgroup on 32 x 8 tiles instead of one per wave -- 1: a workgroup barrier per plane pair (lga_apply_pp_wx / _wxo), 2: progress flags in LDS, the waves within LGAP_WG_SLACK pairs of each other (lga_apply_pp_fx / _fxo); built and emulator-verified in round 4, not yet measured: off
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -579,7 +579,10 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
         if (planar && opts().lga_wg) {                      // one ring per 256-thread workgroup (32 x 8 tiles)
           const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
           if (items < (1ll << 31)) {
-            if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            const bool flags = opts().lga_wg == 2;          // progress flags instead of a barrier per pair-step
+            if (flags && transposed) GA_LAUNCH((lga_apply_pp_fx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            else if (flags) GA_LAUNCH((lga_apply_pp_fx<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            else if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
             else GA_LAUNCH((lga_apply_pp_wx<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
             return check_launch("lga apply (plane pairs, workgroup ring)");
           }
@@ -619,7 +622,10 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
-      if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      const bool flags = opts().lga_wg == 2;                // progress flags instead of a barrier per pair-step
+      if (flags && transposed) GA_LAUNCH((lga_apply_pp_fxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else if (flags) GA_LAUNCH((lga_apply_pp_fxo<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       else GA_LAUNCH((lga_apply_pp_wxo<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       return check_launch("lga apply (plane pairs, interleaved volume, workgroup ring)");
     }
@@ -786,7 +792,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value < 0 || value > 2 ? 0 : value;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
@@ -794,6 +800,8 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
   else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;
+  else if (!strcmp(name, "HIPSIM_FLAG_SLACK")) hipsim::S().flag_slack = value;     // tests: progress-flag polls loosened by `value` steps
+  else if (!strcmp(name, "HIPSIM_WAVE_GREEDY")) hipsim::S().wave_greedy = value ? 1 : 0;   // one wavefront runs as far as its synchronisation lets it
   else if (!strcmp(name, "HIPSIM_LATE_LDS")) hipsim::S().late_lds = value != 0;
   else if (!strcmp(name, "HIPSIM_LGKM_SLACK")) hipsim::S().lgkm_slack = value;     // tests: every counted LDS wait loosened by `value`
   else if (!strcmp(name, "HIPSIM_VMCNT_SLACK")) hipsim::S().vm_slack = value;      // tests: every counted copy wait loosened by `value`

@@ -63,6 +63,7 @@ struct Fiber {
   ucontext_t ctx;
   char *stack = nullptr;
   bool done = false;
+  bool ext_blocked = false;      // its last yield waited for OTHER wavefronts (workgroup barrier, progress-flag poll)
   dim3 tidx;
 };
 
@@ -101,21 +102,33 @@ struct State {
   bool late_lds = false;
   long lds_late_landed = 0;
   int lgkm_slack = 0, vm_slack = 0;
+  int flag_slack = 0;            // tests only: progress-flag polls accept a wave that many steps further behind
   // order in which the runnable threads of a block are resumed between two barriers: 0 = ascending thread index,
   // 1 = descending.  A hand-off through LDS that lacks a barrier is decided by whichever thread runs first; results that
   // are the same in both orders do not depend on that luck.
   int lane_order = 0;
+  // wave_greedy: instead of resuming every thread of the block in turn (which moves all wavefronts forward together), run ONE
+  // wavefront for as long as it can go -- until each of its threads waits for another wavefront -- then the next one.  The
+  // first wavefront scheduled is then as far ahead of the others as the kernel's synchronisation permits, which is what a
+  // hand-off between waves that is too permissive needs in order to show (with lane_order: the last wavefront instead).
+  int wave_greedy = 0;
 };
 
 inline State &S() { static State s; return s; }
 
-inline void yield() { State &s = S(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+inline void yield(bool waits_for_other_waves = true)
+{
+  State &s = S();
+  s.fibers[s.cur].ext_blocked = waits_for_other_waves;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  s.fibers[s.cur].ext_blocked = false;
+}
 
-inline void barrier_wait(Barrier &b, int n)
+inline void barrier_wait(Barrier &b, int n, bool across_waves = true)
 {
   const int gen = b.gen;
   if (++b.count == n) { b.count = 0; b.gen++; }
-  else while (b.gen == gen) yield();
+  else while (b.gen == gen) yield(across_waves);
 }
 
 inline int flat_tid() { State &s = S(); const dim3 &t = s.fibers[s.cur].tidx; return t.x + s.blockDim_.x * (t.y + s.blockDim_.y * t.z); }
@@ -128,7 +141,7 @@ inline void wave_sync()
   State &s = S();
   const int wave = flat_tid() >> 6;
   const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
-  barrier_wait(s.wave_bar[wave], wsize);
+  barrier_wait(s.wave_bar[wave], wsize, false);
 }
 
 inline void dma_land(const State::DmaOp &op) { for (int k = 0; k < op.n; k++) op.dst[k] = op.v[k]; }
@@ -177,7 +190,7 @@ inline int update_dpp(int old, int src, int ctrl)
   const int tid = flat_tid(), wave = tid >> 6, lane = tid & 63;
   const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
   s.xchg[tid] = src;
-  barrier_wait(s.wave_bar[wave], wsize);
+  barrier_wait(s.wave_bar[wave], wsize, false);
   int sl = lane;
   bool valid = true;
   if (ctrl >= 0 && ctrl <= 0xFF) sl = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
@@ -190,7 +203,7 @@ inline int update_dpp(int old, int src, int ctrl)
   else { fprintf(stderr, "hipsim: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
   if (valid && sl >= wsize) valid = false;   // inactive source lane: dest keeps old
   const int v = valid ? s.xchg[wave * 64 + sl] : old;
-  barrier_wait(s.wave_bar[wave], wsize);
+  barrier_wait(s.wave_bar[wave], wsize, false);
   return v;
 }
 
@@ -201,9 +214,9 @@ inline int readlane(int src, int l)
   const int tid = flat_tid(), wave = tid >> 6;
   const int wsize = (s.nthreads - wave * 64) < 64 ? (s.nthreads - wave * 64) : 64;
   s.xchg[tid] = src;
-  barrier_wait(s.wave_bar[wave], wsize);
+  barrier_wait(s.wave_bar[wave], wsize, false);
   const int v = s.xchg[wave * 64 + (l < wsize ? l : 0)];
-  barrier_wait(s.wave_bar[wave], wsize);
+  barrier_wait(s.wave_bar[wave], wsize, false);
   return v;
 }
 
@@ -254,6 +267,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
         for (int t = 0; t < nt; t++) {
           Fiber &f = s.fibers[t];
           f.done = false;
+          f.ext_blocked = false;
           f.tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
           getcontext(&f.ctx);
           f.ctx.uc_stack.ss_sp = f.stack;
@@ -263,13 +277,34 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
         }
         int remaining = nt;
         long spins = 0;
+        const int nwave = (nt + 63) / 64;
         while (remaining > 0) {
-          for (int i = 0; i < nt; i++) {
-            const int t = s.lane_order ? nt - 1 - i : i;
-            if (s.fibers[t].done) continue;
-            s.cur = t;
-            swapcontext(&s.sched, &s.fibers[t].ctx);
-            if (s.fibers[t].done) remaining--;
+          if (s.wave_greedy && nwave > 1) {
+            for (int wi = 0; wi < nwave; wi++) {
+              const int w = s.lane_order ? nwave - 1 - wi : wi;
+              const int t0 = w * 64, t1 = t0 + 64 < nt ? t0 + 64 : nt;
+              for (;;) {                               // this wavefront, until all of its threads wait for another one
+                bool can_go_on = false;
+                for (int i = t0; i < t1; i++) {
+                  const int t = s.lane_order ? t1 - 1 - (i - t0) : i;
+                  if (s.fibers[t].done) continue;
+                  s.cur = t;
+                  swapcontext(&s.sched, &s.fibers[t].ctx);
+                  if (s.fibers[t].done) remaining--;
+                  else if (!s.fibers[t].ext_blocked) can_go_on = true;
+                }
+                if (!can_go_on) break;
+                if (++spins > 100000000L) { fprintf(stderr, "hipsim: deadlock inside a wavefront (divergent wave barrier/DPP?)\n"); abort(); }
+              }
+            }
+          } else {
+            for (int i = 0; i < nt; i++) {
+              const int t = s.lane_order ? nt - 1 - i : i;
+              if (s.fibers[t].done) continue;
+              s.cur = t;
+              swapcontext(&s.sched, &s.fibers[t].ctx);
+              if (s.fibers[t].done) remaining--;
+            }
           }
           if (++spins > 100000000L) { fprintf(stderr, "hipsim: deadlock (divergent barrier/DPP?)\n"); abort(); }
         }

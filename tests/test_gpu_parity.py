@@ -540,8 +540,8 @@ def test_cost_volume_and_regression_cfg3_cfg5_sizes(api, dev, port_oracle, N, C,
                                    (1, 21, 61, 96)])
 @pytest.mark.parametrize("paired", [0, 1])
 def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape, paired):
-    """GANET_LGA_WG=1: the forward / data-backward of API-layout volumes with one LDS ring per 256-thread workgroup (32 x 8
-    tiles; lga_apply_pp_wx / _wxo).  Same arithmetic per pixel as the one-wave kernels: results must agree with theirs to fp32
+    """GANET_LGA_WG=1|2: the forward / data-backward of API-layout volumes with one LDS ring per 256-thread workgroup (32 x 8
+    tiles; lga_apply_pp_wx / _wxo with a barrier per plane pair, lga_apply_pp_fx / _fxo with progress flags).  Same arithmetic per pixel as the one-wave kernels: results must agree with theirs to fp32
     rounding on whole tiles, be bit-reproducible over repeated runs (the hand-off between the four waves is one counted wait +
     one barrier per plane pair: a race would not be deterministic), and agree with the oracle; then once more with the item
     lists each form chooses for itself."""
@@ -563,7 +563,7 @@ def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape
         for mix, segs in ((0, 1), (1, 0)):
             api.set_option("GANET_LGA_MIX", mix)
             api.set_option("GANET_LGA_SEGS", segs)
-            for wg in (0, 1, 1):
+            for wg in (0, 1, 1, 2, 2):
                 api.set_option("GANET_LGA_WG", wg)
                 got = {}
                 chain(api, dev, xn, fn, gyn, 2, 2, want, out=got)
@@ -578,5 +578,6 @@ def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape
     # (bit for bit under the emulator, tests/test_sim_bounds.py; here the two forms are separate instantiations compiled for the
     # device, where the prologue's plain C++ sums may be contracted differently: fp32 rounding is the bar, a stale ring slot is O(1))
     for k in res[0, 0]:
-        assert np.abs(res[0, 0][k] - res[0, 1][k]).max() <= pc.TOL, (k, float(np.abs(res[0, 0][k] - res[0, 1][k]).max()))
-        assert np.abs(res[1, 0][k] - res[1, 1][k]).max() <= pc.TOL, k
+        for wg in (1, 2):
+            assert np.abs(res[0, 0][k] - res[0, wg][k]).max() <= pc.TOL, (k, wg, float(np.abs(res[0, 0][k] - res[0, wg][k]).max()))
+            assert np.abs(res[1, 0][k] - res[1, wg][k]).max() <= pc.TOL, (k, wg)
