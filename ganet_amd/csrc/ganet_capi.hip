@@ -658,6 +658,12 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
   if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  else if (GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
+    sg.tiles_y = (H + 7) / 8;
+    const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
+    if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    else GA_LAUNCH((lga_filter_grad_pp_wgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+  }
   else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
@@ -706,6 +712,13 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
         bool planar = false;
         if constexpr (R == 2) {
           planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
+          if (planar && opts().lga_wg) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
+            sg.tiles_y = (H + 7) / 8;
+            const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
+            if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+            else GA_LAUNCH((lga_filter_grad_pp_wx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+            return check_launch("lga filter grad (plane pairs, workgroup ring)");
+          }
           if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         }
         if (!planar) GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);

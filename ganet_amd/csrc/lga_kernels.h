@@ -1147,6 +1147,59 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 // the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
+// x staged planar into ONE ring per 256-thread workgroup (32 x 8 tiles; GANET_LGA_WG = 1: a barrier per pair-step, = 2: progress flags)
+#define GA_FG_NAME lga_filter_grad_pp_wx
+#define GA_FG_XP 3
+#define GA_FG_GYP 0
+#define GA_FG_WGSYNC 0
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+#define GA_FG_NAME lga_filter_grad_pp_wgypx
+#define GA_FG_XP 3
+#define GA_FG_GYP 1
+#define GA_FG_WGSYNC 0
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+#define GA_FG_NAME lga_filter_grad_pp_fx
+#define GA_FG_XP 3
+#define GA_FG_GYP 0
+#define GA_FG_WGSYNC 1
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+#define GA_FG_NAME lga_filter_grad_pp_fgypx
+#define GA_FG_XP 3
+#define GA_FG_GYP 1
+#define GA_FG_WGSYNC 1
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_gypx
 #define GA_FG_XP 2
 #define GA_FG_GYP 1

@@ -220,7 +220,7 @@ def test_sga_with_reversed_thread_order(sim, port_oracle, reversed_lanes, shape)
 # one after the other: a missing or misplaced workgroup barrier reads a slot quarter another wave has not even requested.
 _WG_SHAPES = [(1, D, 11, 36) for D in (1, 2, 3, 8, 9, 13, 14, 21, 26, 27)] + \
              [(2, 13, 5, 68), (1, 22, 2, 8), (1, 15, 9, 40), (1, 33, 1, 4), (1, 12, 8, 32), (1, 10, 17, 64), (1, 7, 16, 4), (1, 40, 9, 36),
-              (1, 41, 3, 36)]
+              (1, 41, 3, 36), (1, 61, 8, 32)]      # (D >= 34: the filter gradient's steady groups of LGAP_WG_NR = 8 steps; 61: two of them)
 
 
 # GANET_LGA_WG=2 (lga_apply_pp_fx / _fxo): no barrier in the march -- a wave publishes its pair-step in LDS and goes on while
