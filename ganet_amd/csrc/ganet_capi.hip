@@ -619,6 +619,17 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   i64 items;
   float *const none = nullptr;
+  if (x_paired && opts().lga_wg) {                                       // one ring per 256-thread workgroup (32 x 8 tiles)
+    const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
+    if (items < (1ll << 31)) {
+      const bool flags = opts().lga_wg == 2;                // progress flags instead of a barrier per pair-step
+      if (flags && transposed) GA_LAUNCH((lga_apply_pp_fpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else if (flags) GA_LAUNCH((lga_apply_pp_fpi<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else if (transposed) GA_LAUNCH((lga_apply_pp_wpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      else GA_LAUNCH((lga_apply_pp_wpi<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      return check_launch("lga apply (plane pairs, interleaved input, workgroup ring)");
+    }
+  }
   if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
@@ -657,7 +668,13 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  if (x_paired && opts().lga_wg) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
+    sg.tiles_y = (H + 7) / 8;
+    const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
+    if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    else GA_LAUNCH((lga_filter_grad_pp_wxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+  }
+  else if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else if (GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
     sg.tiles_y = (H + 7) / 8;
     const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;

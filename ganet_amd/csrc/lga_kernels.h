@@ -1017,6 +1017,45 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #undef GA_PP_SLOT
 #undef GA_PP_NDC
 #undef GA_PP_Y
+// the same through ONE ring per 256-thread workgroup (GANET_LGA_WG = 1: barrier per pair-step, = 2: progress flags)
+#define GA_PP_NAME lga_apply_pp_wpi
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 4
+#define GA_PP_WGSYNC 0
+#define GA_PP_OUT 0
+#define GA_PP_SLOT 1024
+#define GA_PP_NDC 1
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_WGSYNC
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
+#define GA_PP_NAME lga_apply_pp_fpi
+#define GA_PP_SEG_T LgaSegMix
+#define GA_PP_DECODE lga_decode_item_mix
+#define GA_PP_IN 4
+#define GA_PP_WGSYNC 1
+#define GA_PP_OUT 0
+#define GA_PP_SLOT 1024
+#define GA_PP_NDC 1
+#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
+#include "lga_apply_pp.inc"
+#undef GA_PP_NAME
+#undef GA_PP_SEG_T
+#undef GA_PP_DECODE
+#undef GA_PP_IN
+#undef GA_PP_WGSYNC
+#undef GA_PP_OUT
+#undef GA_PP_SLOT
+#undef GA_PP_NDC
+#undef GA_PP_Y
 #undef GA_PP_Y_PAIRED
 
 // one 4-byte global -> LDS copy per lane, scalar base + 32-bit lane offset: lane l's dword lands at slot + 4 * l
@@ -1147,6 +1186,33 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 // the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
+// x pair-interleaved through ONE ring per 256-thread workgroup
+#define GA_FG_NAME lga_filter_grad_pp_wxp
+#define GA_FG_XP 4
+#define GA_FG_GYP 0
+#define GA_FG_WGSYNC 0
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
+#define GA_FG_NAME lga_filter_grad_pp_fxp
+#define GA_FG_XP 4
+#define GA_FG_GYP 0
+#define GA_FG_WGSYNC 1
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_WGSYNC
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 // x staged planar into ONE ring per 256-thread workgroup (32 x 8 tiles; GANET_LGA_WG = 1: a barrier per pair-step, = 2: progress flags)
 #define GA_FG_NAME lga_filter_grad_pp_wx
 #define GA_FG_XP 3

@@ -291,7 +291,7 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so
  *                         a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average at 240x624).  Default 1
  *                         (measured: forward pass 0.103 -> 0.0955 ms); n > 1: n SIMDs assumed (tests)
- *   GANET_LGA_WG = 0|1|2  the same kernels (and the filter gradient) for API-layout volumes with ONE LDS ring per 256-thread workgroup on 32 x 8 pixel
+ *   GANET_LGA_WG = 0|1|2  the same kernels and the filter gradient (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE LDS ring per 256-thread workgroup on 32 x 8 pixel
  *                         tiles (the halo'd tile staged once for four waves: 12 rows fetched for 8 instead of 24), the four
  *                         waves meeting at a barrier per plane pair (1) or kept within one pair of each other by progress
  *                         flags in LDS (2) | one ring per wave on 32 x 2 tiles (0, default: the workgroup forms are verified

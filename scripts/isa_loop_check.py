@@ -7,7 +7,7 @@ import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = ["lga_apply_pp_fxo", "lga_apply_pp_fx", "lga_apply_pp_wxo", "lga_apply_pp_wx", "lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp_xo", "lga_apply_pp_x", "lga_apply_pp", "lga_filter_grad_pp_wgypx", "lga_filter_grad_pp_fgypx", "lga_filter_grad_pp_wx", "lga_filter_grad_pp_fx", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gypx",
+KERNELS = ["lga_apply_pp_wpi", "lga_apply_pp_fpi", "lga_filter_grad_pp_wxp", "lga_filter_grad_pp_fxp", "lga_apply_pp_fxo", "lga_apply_pp_fx", "lga_apply_pp_wxo", "lga_apply_pp_wx", "lga_apply_pp_pi", "lga_apply_pp_po", "lga_apply_pp_xo", "lga_apply_pp_x", "lga_apply_pp", "lga_filter_grad_pp_wgypx", "lga_filter_grad_pp_fgypx", "lga_filter_grad_pp_wx", "lga_filter_grad_pp_fx", "lga_filter_grad_pp_xp", "lga_filter_grad_pp_gypx",
            "lga_filter_grad_pp_gyp", "lga_filter_grad_pp_x", "lga_filter_grad_pp"]
 
 
