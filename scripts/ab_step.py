@@ -13,6 +13,23 @@ from ganet_amd import _native
 dev = torch.device("cuda:0")
 graphs = {}
 DEFAULTS = {}
+RESET = ("GANET_SGA_TILED", "GANET_LGA_WG", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
+
+
+def reset_options(lib, libname, defaults):
+    """options are process-wide in a loaded library (and a library loaded twice is ONE library): every entry starts from that
+    library's own defaults, whatever an earlier entry of the list set"""
+    if libname not in defaults:
+        defaults[libname] = {}
+        for k in RESET:
+            try:
+                defaults[libname][k] = lib.get_option(k)
+            except Exception:                                  # (an older build of the library: no such option / no ganet_get_option)
+                pass
+    for k, v in defaults[libname].items():
+        lib.set_option(k, v)
+
+
 inp = bench.make_inputs(dev)
 pool = torch.cuda.graph_pool_handle()
 for idx, name in enumerate(sys.argv[1:]):
@@ -20,12 +37,7 @@ for idx, name in enumerate(sys.argv[1:]):
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
     os.environ.pop("GANET_LGA_EDGES", None)
     # options are process-wide in a loaded library: every entry starts from that library's own defaults
-    try:
-        if libname not in DEFAULTS:
-            DEFAULTS[libname] = _native._LIB.get_option("GANET_SGA_TILED")
-        _native._LIB.set_option("GANET_SGA_TILED", DEFAULTS[libname])
-    except Exception:
-        pass
+    reset_options(_native._LIB, libname, DEFAULTS)
     for kv in filter(None, optstr.split(",")):
         k, v = kv.split("=")
         if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE", "GANET_LGA_EDGES"):      # read by the Python layer from the environment at every call
