@@ -2,6 +2,8 @@
 libganet_hip.so driven through its C ABI, against the committed golden fixtures (generated from
 the reference's own kernel bodies) and the CPU oracle on the same seeded inputs.
 Bar: direction mask / forward volumes bit-exact, fp32 gradients within 1e-4 max-abs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -539,6 +541,10 @@ def test_cost_volume_and_regression_cfg3_cfg5_sizes(api, dev, port_oracle, N, C,
 @pytest.mark.parametrize("shape", [(1, 48, 240, 624), (1, 33, 7, 36), (2, 9, 3, 64), (1, 5, 66, 132), (1, 64, 13, 100), (1, 2, 2, 4),
                                    (1, 21, 61, 96)])
 @pytest.mark.parametrize("paired", [0, 1])
+@pytest.mark.skipif(os.environ.get("GANET_TEST_WG") != "1",
+                    reason="the workgroup-ring kernels (GANET_LGA_WG, default off) were written after round 4's last GPU minute and "
+                           "have only run on the emulator: their first time on a device is scripts/gpu_r5_wg.sh, under a timeout of "
+                           "its own, not a driver run (GANET_TEST_WG=1 enables this test)")
 def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape, paired):
     """GANET_LGA_WG=1|2: the forward / data-backward of API-layout volumes with one LDS ring per 256-thread workgroup (32 x 8
     tiles; lga_apply_pp_wx / _wxo with a barrier per plane pair, lga_apply_pp_fx / _fxo with progress flags).  Same arithmetic per pixel as the one-wave kernels: results must agree with theirs to fp32
