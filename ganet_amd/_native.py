@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -42,6 +42,7 @@ _PROTOS = {
     "ganet_lga_apply_paired": [_P] * 3 + [_I] * 8 + [_P],
     "ganet_lga_apply_paired_edges": [_P] * 4 + [_I] * 8 + [_P],
     "ganet_lga_filter_grad_paired": [_P] * 3 + [_I] * 8 + [_P],
+    "ganet_lga2_filter_grad": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_cost_volume_forward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_disparity_regression_forward": [_P] * 2 + [_I] * 4 + [_P],
@@ -103,6 +104,10 @@ class CApi:
 
     def last_error(self):
         return self._lib.ganet_last_error().decode("utf-8", "replace")
+
+    def has(self, name):
+        """does this build export `name`? (strict=False loads of older builds)"""
+        return hasattr(self._lib, name)
 
     def call(self, name, *args):
         rc = getattr(self._lib, name)(*args)

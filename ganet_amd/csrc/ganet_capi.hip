@@ -686,6 +686,25 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
 }
 
+// both filter-gradient passes of an LGA2's backward in one launch (lga_filter_grad_pp_lga2): gf (=|+=) gF(t1p, gy) + gF(x, gt1p)
+int launch_lga2_gf(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D, int H, int W,
+                   int acc, hipStream_t st)
+{
+  if ((i64)H * W >= (1ll << 28) || W % 4 != 0 || !GA_LGA_PLANAR || !aligned16(t1p) || !aligned16(gy) || !aligned16(x) || !aligned16(gt1p))
+    return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: needs W % 4 == 0, planes below 2^28 pixels and 16-byte aligned volumes "
+                                     "(otherwise: two ganet_lga_filter_grad_paired calls)");
+  LgaGeom geo;
+  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
+  LgaSeg sg;
+  sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
+  sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
+  sg.nseg = 1; sg.seg_len = D;
+  const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
+  if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: too many tiles");
+  GA_LAUNCH((lga_filter_grad_pp_lga2<2, 3, 0>), dim3((unsigned)items), dim3(64), st, t1p, gy, x, gt1p, gf, geo, sg, acc);
+  return check_launch("lga2 filter grad (both passes, plane pairs)");
+}
+
 // one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
 template <int R>
 int launch_lga_fwd_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D, int H, int W,
@@ -1152,6 +1171,15 @@ GA_EXPORT int ganet_lga_filter_grad_paired(const float *x, const float *gy, floa
   if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: radius 2 only");
   if (!x_paired && !gy_paired) return launch_lga_gf<2>(x, gy, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
   return launch_lga_gf_paired(x, gy, gf, B, D, H, W, accumulate_gf != 0, x_paired != 0, (hipStream_t)stream);
+}
+
+GA_EXPORT int ganet_lga2_filter_grad(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D,
+                                     int H, int W, int radius, int accumulate_gf, void *stream)
+{
+  if (!t1p || !gy || !x || !gt1p || !gf) return fail(GANET_E_INVALID, "ganet_lga2_filter_grad: null pointer");
+  GA_TRY(check_lga("ganet_lga2_filter_grad", B, D, H, W, radius));
+  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: radius 2 only");
+  return launch_lga2_gf(t1p, gy, x, gt1p, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,

@@ -1186,6 +1186,27 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #undef GA_FG_SLOT
 #undef GA_FG_NDC
 // the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
+// both filter-gradient passes of an LGA2's backward in one kernel: gF(t1 pair-interleaved, gy API layout) + gF(x API layout staged
+// planar, g_t1 pair-interleaved), one write of gf (ganet_lga2_filter_grad; W % 4 == 0, 16-byte aligned volumes)
+#define GA_FG_NAME lga_filter_grad_pp_lga2
+#define GA_FG_FUSED 1
+#define GA_FG_XP_A 1
+#define GA_FG_GYP_A 0
+#define GA_FG_XP_B 2
+#define GA_FG_GYP_B 1
+#define GA_FG_SLOT 512
+#define GA_FG_NDC 2
+#include "lga_filter_grad_pp.inc"
+#undef GA_FG_NAME
+#undef GA_FG_FUSED
+#undef GA_FG_XP
+#undef GA_FG_GYP
+#undef GA_FG_XP_A
+#undef GA_FG_GYP_A
+#undef GA_FG_XP_B
+#undef GA_FG_GYP_B
+#undef GA_FG_SLOT
+#undef GA_FG_NDC
 // x pair-interleaved through ONE ring per 256-thread workgroup
 #define GA_FG_NAME lga_filter_grad_pp_wxp
 #define GA_FG_XP 4

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 8
+#define GANET_ABI_VERSION 9
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -189,6 +189,15 @@ int ganet_lga_apply_paired_edges(const float *x, const float *f, float *y, float
  * into.  radius 2 only, W even, 16-byte aligned volumes. */
 int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
                                  int accumulate_gf, int x_paired, int gy_paired, void *stream);
+
+/* ABI v9.  BOTH filter-gradient passes of a two-pass chain's backward (Lga2Function.backward, functions/GANet.py:190-203: two
+ * lga_cuda_backward calls whose lga_filter_backward halves, GANet_kernel.cu:1177-1216, add into the same gradFilters) in one
+ * launch:  gf (=|+=)  gF(t1p, gy) + gF(x, gt1p)  with t1p = the chain's intermediate and gt1p = its gradient, both
+ * pair-interleaved (ganet_lga_apply_paired), gy and x in the API layout.  The second pass goes on adding into the
+ * accumulators of the first: gf is written once instead of written, read and written again, and one launch goes.
+ * radius 2, W % 4 == 0, 16-byte aligned volumes; GANET_E_UNSUPPORTED otherwise (then: two ganet_lga_filter_grad_paired calls). */
+int ganet_lga2_filter_grad(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D, int H, int W,
+                           int radius, int accumulate_gf, void *stream);
 
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,

@@ -19,6 +19,35 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.mark.skipif(__import__("os").environ.get("GANET_TEST_WG") != "1",
+                    reason="GANET_LGA_FG_FUSED / GANET_LGA_WG (default off) were written after round 4's last GPU minute: first device "
+                           "run in scripts/gpu_r5_wg.sh (GANET_TEST_WG=1 enables this test)")
+@pytest.mark.parametrize("fused,wg", [("1", 0), ("1", 1), ("0", 2)])
+def test_lga2_module_with_round5_candidates(torch_mod, port_oracle, monkeypatch, fused, wg):
+    """LGA2 through autograd with the fused two-pass filter gradient (ganet_lga2_filter_grad) and / or the workgroup rings"""
+    monkeypatch.setenv("GANET_LGA_FG_FUSED", fused)
+    torch = torch_mod
+    import torch.nn.functional as F
+    import ganet_amd.modules.GANet as M
+    from ganet_amd import _native
+    _native.lib().set_option("GANET_LGA_WG", wg)
+    try:
+        torch.manual_seed(11)
+        x = torch.randn((2, 41, 21, 40), device="cuda", requires_grad=True)
+        f = F.normalize(torch.randn((2, 75, 21, 40), device="cuda"), p=1, dim=1).requires_grad_()
+        gy = torch.randn_like(x)
+        y = M.LGA2(radius=2)(x, f)
+        y.backward(gy)
+        torch.cuda.synchronize()
+    finally:
+        _native.lib().set_option("GANET_LGA_WG", 0)
+    o_y, ins = port_oracle.lga_chain_forward(_np(x), _np(f), 2, 2)
+    o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy), 2)
+    assert np.abs(_np(y) - o_y).max() <= pc.TOL
+    assert np.abs(_np(x.grad) - o_gx).max() <= pc.TOL
+    assert np.abs(_np(f.grad) - o_gf).max() <= pc.TOL
+
+
 @pytest.mark.parametrize("save_mode", ["", "recompute"])
 def test_sga_module_autograd(torch_mod, port_oracle, monkeypatch, save_mode):
     torch = torch_mod
