@@ -259,6 +259,10 @@ def roofline_from_stages(stages):
                "step_ms": round(step_ms, 4), "bound": "hbm", "frac": round(achieved / HBM_PEAK_GBS, 4),
                "alg_bytes_per_launch": int(bytes_per_launch), "hbm_GBs": round(achieved, 1),
                "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if traffic is not None:
+            # what the launch actually moves per second at the L2 <-> fabric boundary (measured bytes / measured time): a family
+            # far below its algorithmic roofline may still sit near the fabric's rate because of what it re-reads
+            row["traffic_GBs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
         if traffic is not None and unit_traffic is not None:
             unit_traffic += traffic * len(keys) * mult
         else:
