@@ -393,6 +393,9 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_WG_SLACK
 #define LGAP_WG_SLACK 1   // flag-synchronised workgroup ring: pair-steps a wave may be ahead of the slowest wave of its workgroup
 #endif
+#ifndef LGAP_WG_NR_FG
+#define LGAP_WG_NR_FG LGAP_WG_NR      // the filter gradient's x ring (its steady groups are NR steps long: at D = 193, 8 slots leave 17 of 97 steps to the general body, 6 leave 13)
+#endif
 #ifndef LGAP_WG_NR
 #define LGAP_WG_NR 8      // ring slots (4 KB each) of the workgroup-shared ring: 34 KB per workgroup, three workgroups per CU (see the march of lga_apply_pp.inc)
 #endif
