@@ -3,7 +3,8 @@
 # launches of the step; built and emulator-verified in round 4, never run on a GPU).
 # (1) their parity tests, under a timeout of their own: a hang here must not take the call with it;
 # (2) whole-step A/B against the default kernels on one box (hipGraph replay, interleaved: +-0.2 %), plus ring depths / slack if the
-#     variant libraries were built:  python scripts/build_variants.py wg6:-DLGAP_WG_NR=6 wgf6:-DLGAP_WG_NR_FG=6 wg10:-DLGAP_WG_NR=10 wgs2:-DLGAP_WG_NR=10,-DLGAP_WG_SLACK=2
+#     variant libraries were built:  python scripts/build_variants.py wg6:-DLGAP_WG_NR=6 wgf6:-DLGAP_WG_NR_FG=6 wg10:-DLGAP_WG_NR=10,-DLGAP_WG_NR_FG=8 wgs2:-DLGAP_WG_NR=10,-DLGAP_WG_SLACK=2,-DLGAP_WG_NR_FG=8
+#     (each checked under the emulator first: python scripts/sim_wg_variants.py <flags>; the filter gradient's ring stays at 8 slots: 3 workgroups of 49 KB per CU)
 # (3) the LGA kernels of the step one by one, same settings; (4) fabric traffic of the step with the rings on (the point of them:
 #     x over-fetch 1.5 - 1.9 x -> ?), one PMC pass.                                  bash scripts/gpu_r5_wg.sh <tag>
 TAG=${1:-r8a}
