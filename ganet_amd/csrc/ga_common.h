@@ -53,11 +53,13 @@ GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 #define GA_KEEP_F2(v) ((void)0)
 #define GA_OPAQUE_S(v) ((void)0)
 #define GA_OPAQUE_V(v) ((void)0)
+#define GA_OPAQUE_VF(v) ((void)0)
 #define GA_SCHED_FENCE() ((void)0)
 #else
 #define GA_KEEP_F2(v) asm volatile("" : "+v"(v))
 #define GA_OPAQUE_S(v) asm volatile("" : "+s"(v))   // uniform value the optimiser may not reason about
 #define GA_OPAQUE_V(v) asm volatile("" : "+v"(v))   // the same for a per-lane value
+#define GA_OPAQUE_VF(v) asm("" : "+v"(v))          // ... without `volatile`: only hides where the value came from (may be moved, dropped if unused)
 // nothing is scheduled across this point: used to pin a hand-chosen instruction interleaving
 #if defined(GA_NO_SCHED_FENCE)
 #define GA_SCHED_FENCE() ((void)0)
@@ -191,6 +193,10 @@ GA_DEV int lane_id()
 enum : int {
   DPP_QP_XOR1 = 0xB1,   // quad_perm [1,0,3,2]
   DPP_QP_XOR2 = 0x4E,   // quad_perm [2,3,0,1]
+  DPP_QP_BCAST0 = 0x00, // quad_perm [0,0,0,0]: every lane of a quad receives lane 0's value
+  DPP_QP_BCAST1 = 0x55,
+  DPP_QP_BCAST2 = 0xAA,
+  DPP_QP_BCAST3 = 0xFF,
   DPP_ROW_SHL1 = 0x101,
   DPP_ROW_SHR1 = 0x111,
   DPP_ROW_MIRROR = 0x140,
@@ -207,8 +213,7 @@ template <int CTRL> GA_DEV int dpp_src_lane(int lane, bool &valid)
 {
   const int row = lane & ~15, r = lane & 15;
   valid = true;
-  if (CTRL == DPP_QP_XOR1) return lane ^ 1;
-  if (CTRL == DPP_QP_XOR2) return lane ^ 2;
+  if (CTRL >= 0 && CTRL <= 0xFF) return (lane & ~3) | ((CTRL >> (2 * (lane & 3))) & 3);      // any quad_perm
   if (CTRL == DPP_ROW_SHL1) { valid = r < 15; return lane + 1; }
   if (CTRL == DPP_ROW_SHR1) { valid = r > 0; return lane - 1; }
   if (CTRL == DPP_ROW_MIRROR) return row + (15 - r);

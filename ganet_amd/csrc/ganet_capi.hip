@@ -65,6 +65,7 @@ struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
+  std::atomic<int> point_q4{0};     // SGA per-pixel gradient kernel with four pixels of ONE direction per lane (sga_bwd_point_q4: 16-byte loads, same per-lane state); built in round 4 after the last GPU minute, not yet measured: off
   std::atomic<int> lga_wg{0};       // plane-pair forward / data-backward of API-layout volumes: ONE ring per 256-thread workgroup on 32 x 8 tiles instead of one per wave -- 1: a workgroup barrier per plane pair (lga_apply_pp_wx / _wxo), 2: progress flags in LDS, the waves within LGAP_WG_SLACK pairs of each other (lga_apply_pp_fx / _fxo); built and emulator-verified in round 4, not yet measured: off
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
@@ -87,6 +88,7 @@ void load_env_options()
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_LGA_WG", g_opt.lga_wg);
+  geti("GANET_SGA_POINT_Q4", g_opt.point_q4);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
@@ -478,6 +480,23 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
+  if (ndir == 4 && opts().point_q4 && W % 4 == 0) {      // four pixels of one direction per lane: 16-byte loads (not measured yet: off)
+    // (32-bit byte offsets inside the kernel: a volume, and the directions' volumes measured from direction 0's, below 4 GB)
+    const i64 vbytes = 4 * npix * D;
+    bool al = aligned16(x) && aligned16(gx) && vbytes < (1ll << 32);
+    for (int q = 0; q < 4; q++) {
+      const i64 dg = (const char *)pa.G[q] - (const char *)pa.G[0], da = (const char *)pa.A[q] - (const char *)pa.A[0];
+      al = al && aligned16(pa.G[q]) && aligned16(pa.A[q]) && aligned16(pa.g[q]) && aligned16(pa.gw[q]) && pa.dir[q] == q &&
+           dg >= 0 && da >= 0 && dg + vbytes < (1ll << 32) && da + vbytes < (1ll << 32);
+    }
+    if (al) {
+      if (accumulate && tiled) GA_LAUNCH((sga_bwd_point_q4<true, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+      else if (accumulate) GA_LAUNCH((sga_bwd_point_q4<true, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+      else if (tiled) GA_LAUNCH((sga_bwd_point_q4<false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+      else GA_LAUNCH((sga_bwd_point_q4<false, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
+      return check_launch("sga per-pixel gradients (pixel quads)");
+    }
+  }
   if (ndir == 4 && !accumulate && tiled) GA_LAUNCH((sga_bwd_point<4, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
@@ -825,6 +844,7 @@ GA_EXPORT int ganet_get_option(const char *name)
   if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
   if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
   if (!strcmp(name, "GANET_LGA_WG")) return g_opt.lga_wg;
+  if (!strcmp(name, "GANET_SGA_POINT_Q4")) return g_opt.point_q4;
   if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
   if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
   if (!strcmp(name, "GANET_SGA_WIDE_COL")) return g_opt.wide_col;
@@ -842,6 +862,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
   else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value < 0 || value > 2 ? 0 : value;
+  else if (!strcmp(name, "GANET_SGA_POINT_Q4")) g_opt.point_q4 = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;

@@ -293,6 +293,9 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_WIDE_COL=0|1|2  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
  *                         D <= 192): never | for inputs with few column blocks and D >= 96 (default; measured on
  *                         [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40) | whenever the kernel applies (tests)
+ *   GANET_SGA_POINT_Q4 = 0|1  the per-pixel gradient kernel of ganet_sga_backward / ganet_sga_backward_point with one pixel and four
+ *                         directions per lane (default) | four pixels of ONE direction per lane, 16-byte loads (W % 4 == 0,
+ *                         16-byte aligned volumes below 4 GB; verified under the emulator, not measured yet)
  *   GANET_LGA_WAVE = 0|1  LGA kernels: 256-thread tiles (any radius; the fallback) | wave-autonomous, LDS-DMA, FMAs packed
  *                         along plane pairs (radius <= 2; default)
  *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)

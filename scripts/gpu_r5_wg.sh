@@ -13,8 +13,9 @@ OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT; cd $ROOT
 export TMPDIR=/tmp
 GANET_TEST_WG=1 timeout -k 5 420 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "workgroup_ring" > $OUT/tests_wg.log 2>&1; echo "wg tests rc=$?"; tail -3 $OUT/tests_wg.log
 # the fused two-pass filter gradient (ganet_lga2_filter_grad; GANET_LGA_FG_FUSED=1 in the Python layer): checked inside the paired chains
-GANET_TEST_WG=1 timeout -k 5 300 python -m pytest tests/test_gpu_bounds.py tests/test_gpu_parity.py tests/test_gpu_modules.py -x -q -m gpu -k "lga_chain_on_end_aligned or paired or round5" > $OUT/tests_fused.log 2>&1; echo "fused-fg tests rc=$?"; tail -3 $OUT/tests_fused.log
-LIBS="libganet_hip.so libganet_hip.so@GANET_LGA_FG_FUSED=1 libganet_hip.so@GANET_LGA_WG=1 libganet_hip.so@GANET_LGA_WG=2 libganet_hip.so@GANET_LGA_WG=1,GANET_LGA_MIX=0 libganet_hip.so@GANET_LGA_WG=2,GANET_LGA_SEGS=2"
+GANET_TEST_WG=1 timeout -k 5 300 python -m pytest tests/test_gpu_bounds.py tests/test_gpu_parity.py tests/test_gpu_modules.py -x -q -m gpu -k "lga_chain_on_end_aligned or paired or round5 or pixel_quads" > $OUT/tests_fused.log 2>&1; echo "fused-fg tests rc=$?"; tail -3 $OUT/tests_fused.log
+LIBS="libganet_hip.so libganet_hip.so@GANET_SGA_POINT_Q4=1 libganet_hip.so@GANET_LGA_FG_FUSED=1 libganet_hip.so@GANET_LGA_WG=1 libganet_hip.so@GANET_LGA_WG=2 libganet_hip.so@GANET_LGA_WG=1,GANET_LGA_MIX=0 libganet_hip.so@GANET_LGA_WG=2,GANET_LGA_SEGS=2"
+[ -f ganet_amd/libganet_hip_q4w5.so ] && LIBS="$LIBS libganet_hip_q4w5.so@GANET_SGA_POINT_Q4=1"      # python scripts/build_variants.py q4w5:-DGA_POINT_Q4_WAVES=5
 for V in wg6 wgf6 wg10 wgs2; do [ -f ganet_amd/libganet_hip_$V.so ] && LIBS="$LIBS libganet_hip_$V.so@GANET_LGA_WG=1 libganet_hip_$V.so@GANET_LGA_WG=2"; done
 timeout -k 5 400 python scripts/ab_step.py $LIBS > $OUT/ab_step_wg.txt 2>&1; echo "ab_step rc=$?"; tail -14 $OUT/ab_step_wg.txt
 timeout -k 5 240 python scripts/ab_lga_stages.py libganet_hip.so libganet_hip.so@GANET_LGA_WG=1 libganet_hip.so@GANET_LGA_WG=2 > $OUT/ab_lga_stages_wg.txt 2>&1; echo "ab_lga_stages rc=$?"; tail -14 $OUT/ab_lga_stages_wg.txt

@@ -113,7 +113,7 @@ def run_sga_forward(api, dev, x, gs):
     return dx, dg, A, out, mask, kp
 
 
-def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
+def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True, results=None):
     """want: dict(out, mask(uint8), gx, gw0..gw3, optional A0..A3) from the oracle/golden.
     per_dir=False skips the cross-check of the per-direction entry point (large volumes)."""
     N, C, D, H, W = x.shape
@@ -180,7 +180,28 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True):
     for d in range(4):
         err[f"gw{d}"] = float(np.abs(dev.host(gw[d]) - want[f"gw{d}"]).max())
     assert max(err.values()) <= TOL, err
+    if results is not None:                  # (`results`: dict that receives the gradients)
+        results["gx"] = dev.host(gx)
+        for d in range(4):
+            results[f"gw{d}"] = dev.host(gw[d])
     return err
+
+
+def run_sga_backward_only(api, dev, x, gs, go):
+    """forward + backward through the composite entries, gradients as host arrays (no oracle: the caller compares runs)"""
+    N, C, D, H, W = x.shape
+    dx, dg, A, out, mask, kp = run_sga_forward(api, dev, x, gs)
+    dgo = dev.to(go)
+    gx = dev.empty(x.shape)
+    gw = [dev.empty(gs[0].shape) for _ in range(4)]
+    G = dev.empty((4,) + x.shape)
+    api.call("ganet_sga_backward", dev.ptr(dx), *[dev.ptr(g) for g in dg], dev.ptr(A), dev.ptr(mask), dev.ptr(kp),
+             dev.ptr(dgo), dev.ptr(G), dev.ptr(gx), *[dev.ptr(g) for g in gw], N, C, D, H, W, dev.stream)
+    dev.sync()
+    res = {"gx": dev.host(gx)}
+    for d in range(4):
+        res[f"gw{d}"] = dev.host(gw[d])
+    return res
 
 
 def check_sga_compat(api, dev, x, gs, go, want):

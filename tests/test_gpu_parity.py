@@ -587,3 +587,33 @@ def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape
         for wg in (1, 2):
             assert np.abs(res[0, 0][k] - res[0, wg][k]).max() <= pc.TOL, (k, wg, float(np.abs(res[0, 0][k] - res[0, wg][k]).max()))
             assert np.abs(res[1, 0][k] - res[1, wg][k]).max() <= pc.TOL, (k, wg)
+
+
+@pytest.mark.skipif(os.environ.get("GANET_TEST_WG") != "1",
+                    reason="GANET_SGA_POINT_Q4 (default off) was written after round 4's last GPU minute and has only run on the emulator: "
+                           "first device run in scripts/gpu_r5_wg.sh (GANET_TEST_WG=1 enables this test)")
+@pytest.mark.parametrize("shape", [(1, 32, 65, 80, 208), (1, 48, 33, 40, 104), (2, 2, 17, 12, 48), (1, 1, 5, 3, 8), (1, 3, 9, 7, 20)])
+def test_sga_point_kernel_with_pixel_quads(api, dev, port_oracle, shape):
+    """sga_bwd_point_q4 (four pixels of one direction per lane) at the model's SGA shapes and small ragged ones: gradients against
+    the one-pixel-per-lane kernel (fp32 rounding: the four directions' gradX terms are summed in a different order) and, where
+    the oracle is quick, against the oracle"""
+    x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+    res = {}
+    for q4 in (0, 1, 1):
+        api.set_option("GANET_SGA_POINT_Q4", q4)
+        try:
+            got = pc.run_sga_backward_only(api, dev, x, gs, go)
+        finally:
+            api.set_option("GANET_SGA_POINT_Q4", 0)
+        if q4 in res:
+            assert all(np.array_equal(got[k], res[q4][k]) for k in got), "not reproducible"
+        res[q4] = got
+        dev.release()
+    for k in res[0]:
+        assert np.abs(res[0][k] - res[1][k]).max() <= pc.TOL, (k, float(np.abs(res[0][k] - res[1][k]).max()))
+    if x.size <= 4_000_000:
+        out, tmp, mask = port_oracle.sga_forward(x, *gs)
+        grads = port_oracle.sga_backward(x, *gs, tmp, mask, go)
+        assert np.abs(res[1]["gx"] - grads[0]).max() <= pc.TOL
+        for d in range(4):
+            assert np.abs(res[1][f"gw{d}"] - grads[1 + d]).max() <= pc.TOL

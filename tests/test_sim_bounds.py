@@ -376,3 +376,17 @@ def test_lga_workgroup_ring_bit_identical_to_one_wave_kernels(sim, port_oracle, 
         sim.set_option("GANET_LGA_WG", 0)
         sim.set_option("GANET_LGA_MIX", 1)
         sim.set_option("GANET_LGA_SEGS", 0)
+
+
+@pytest.mark.parametrize("guard", ["end", "start"])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1, 4), (1, 2, 3, 2, 8), (1, 1, 16, 5, 16), (2, 1, 17, 3, 20), (1, 1, 33, 7, 12), (1, 2, 65, 2, 36),
+                                   (1, 3, 4, 16, 32), (1, 1, 48, 8, 48)])
+def test_sga_point_kernel_with_pixel_quads_guarded(sim, port_oracle, shape, guard):
+    """GANET_SGA_POINT_Q4: 16-byte loads of the forward volume a row or a column off the lane's quad -- the first / last quad of the
+    first / last slice must not reach outside the volumes (every buffer ends at, or begins behind, an inaccessible page)"""
+    sim.set_option("GANET_SGA_POINT_Q4", 1)
+    try:
+        x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
+        pc.check_sga_forward_backward(sim, pc.NumpyDev(guard), x, gs, go, _sga_want(port_oracle, x, gs, go))
+    finally:
+        sim.set_option("GANET_SGA_POINT_Q4", 0)
