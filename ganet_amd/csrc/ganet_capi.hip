@@ -66,7 +66,7 @@ struct Options {
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
   std::atomic<int> point_q4{0};     // SGA per-pixel gradient kernel with four pixels of ONE direction per lane (sga_bwd_point_q4: 16-byte loads, same per-lane state); built in round 4 after the last GPU minute, not yet measured: off
-  std::atomic<int> lga_wg{0};       // plane-pair forward / data-backward of API-layout volumes: ONE ring per 256-thread workgroup on 32 x 8 tiles instead of one per wave -- 1: a workgroup barrier per plane pair (lga_apply_pp_wx / _wxo), 2: progress flags in LDS, the waves within LGAP_WG_SLACK pairs of each other (lga_apply_pp_fx / _fxo); built and emulator-verified in round 4, not yet measured: off
+  std::atomic<int> lga_wg{0};       // plane-pair LGA kernels (forward / data-backward and filter gradient, API-layout and pair-interleaved operands): ONE x ring per 256-thread workgroup on 32 x 8 tiles instead of one per wave -- 1: a workgroup barrier per plane pair (lga_apply_pp_w*, lga_filter_grad_pp_w*), 2: progress flags in LDS, the waves within LGAP_WG_SLACK pairs of each other (lga_apply_pp_f*, lga_filter_grad_pp_f*); built and emulator-verified in round 4, not yet measured: off
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
