@@ -22,7 +22,7 @@ def _np(t):
 @pytest.mark.skipif(__import__("os").environ.get("GANET_TEST_WG") != "1",
                     reason="GANET_LGA_FG_FUSED / GANET_LGA_WG (default off) were written after round 4's last GPU minute: first device "
                            "run in scripts/gpu_r5_wg.sh (GANET_TEST_WG=1 enables this test)")
-@pytest.mark.parametrize("fused,wg", [("1", 0), ("1", 1), ("0", 2)])
+@pytest.mark.parametrize("fused,wg", [("1", 0), ("1", 1)] + ([("0", 2)] if "2" in __import__("os").environ.get("GANET_TEST_WG_FORMS", "1,2") else []))
 def test_lga2_module_with_round5_candidates(torch_mod, port_oracle, monkeypatch, fused, wg):
     """LGA2 through autograd with the fused two-pass filter gradient (ganet_lga2_filter_grad) and / or the workgroup rings"""
     monkeypatch.setenv("GANET_LGA_FG_FUSED", fused)
