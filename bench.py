@@ -145,6 +145,12 @@ def stage_timings(inp, iters=5, only=None):
         ("lga_bwd_filter_grad_1", lambda: lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
         ("lga_bwd_data_1", lambda: lib.call("ganet_lga_apply_paired_edges", p(gtp), p(f), p(gxl), p(edge), B, DL, HL, WL, RADIUS, 1, 1, 0, st)),
     ]
+    if os.environ.get("GANET_LGA_FG_FUSED", "0") == "1" and WL % 4 == 0:
+        # what Lga2Function.backward issues with that switch: the first data-backward, then BOTH filter-gradient passes in one launch
+        calls = [c for c in calls if not c[0].startswith("lga_bwd_filter_grad")]
+        i = next(k for k, c in enumerate(calls) if c[0] == "lga_bwd_data_2") + 1
+        calls.insert(i, ("lga_bwd_filter_grad_fused", lambda: lib.call("ganet_lga2_filter_grad", p(tp), p(gy), p(xl), p(gtp), p(gf),
+                                                                    B, DL, HL, WL, RADIUS, 0, st)))
     if only is not None:          # (development A/B scripts: one op's kernels, e.g. with a library build that lacks the newer entries)
         calls = [c for c in calls if c[0].startswith(only)]
     for _ in range(2):
@@ -167,7 +173,7 @@ def stage_timings(inp, iters=5, only=None):
         return res
     # per PASS, as earlier rounds reported the LGA2 chain (mean of its two passes)
     res["lga_fwd_pass"] = (res["lga_fwd_apply_1"] + res["lga_fwd_apply_2"]) / 2
-    res["lga_bwd_pass"] = (res["lga_bwd_filter_grad_2"] + res["lga_bwd_data_2"] + res["lga_bwd_filter_grad_1"] + res["lga_bwd_data_1"]) / 2
+    res["lga_bwd_pass"] = sum(v for k, v in res.items() if k.startswith(("lga_bwd_filter_grad", "lga_bwd_data"))) / 2
     return res
 
 
