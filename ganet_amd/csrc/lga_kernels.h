@@ -858,14 +858,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC ND
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 
 // API layout in and out, the input staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x; radius 2)
 #define GA_PP_NAME lga_apply_pp_x
@@ -877,14 +869,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 
 // ... the waves kept within LGAP_WG_SLACK pair-steps of each other by progress flags in LDS instead of a barrier per step (GANET_LGA_WG=2)
 #define GA_PP_NAME lga_apply_pp_fx
@@ -897,15 +881,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_WGSYNC
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 
 // API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WG)
 #define GA_PP_NAME lga_apply_pp_wx
@@ -917,14 +892,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 
 #define GA_PP_Y_PAIRED(d) yb[((i64)((d) >> 1) * geo.HW + pix) * 2 + ((d) & 1)]
 // API layout in, pair-interleaved out (first pass of an LGA2; data-backward of its second pass)
@@ -937,14 +904,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC ND
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 // the same with the API-layout input staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
 #define GA_PP_NAME lga_apply_pp_xo
 #define GA_PP_SEG_T LgaSegMix
@@ -955,14 +914,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 // ... the waves kept within LGAP_WG_SLACK pair-steps of each other by progress flags in LDS instead of a barrier per step (GANET_LGA_WG=2)
 #define GA_PP_NAME lga_apply_pp_fxo
 #define GA_PP_SEG_T LgaSegMix
@@ -974,15 +925,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_WGSYNC
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 
 // the same with ONE planar ring per 256-thread workgroup (GANET_LGA_WG)
 #define GA_PP_NAME lga_apply_pp_wxo
@@ -994,14 +936,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 // pair-interleaved in, API layout out (second pass of an LGA2; data-backward of its first pass)
 #define GA_PP_NAME lga_apply_pp_pi
 #define GA_PP_SEG_T LgaSegMix
@@ -1012,14 +946,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 // the same through ONE ring per 256-thread workgroup (GANET_LGA_WG = 1: barrier per pair-step, = 2: progress flags)
 #define GA_PP_NAME lga_apply_pp_wpi
 #define GA_PP_SEG_T LgaSegMix
@@ -1031,15 +957,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_WGSYNC
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 #define GA_PP_NAME lga_apply_pp_fpi
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
@@ -1050,15 +967,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 1
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-#undef GA_PP_NAME
-#undef GA_PP_SEG_T
-#undef GA_PP_DECODE
-#undef GA_PP_IN
-#undef GA_PP_WGSYNC
-#undef GA_PP_OUT
-#undef GA_PP_SLOT
-#undef GA_PP_NDC
-#undef GA_PP_Y
 #undef GA_PP_Y_PAIRED
 
 // one 4-byte global -> LDS copy per lane, scalar base + 32-bit lane offset: lane l's dword lands at slot + 4 * l
@@ -1146,11 +1054,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT PC::SLOT
 #define GA_FG_NDC ND
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 // x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
 // x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x; radius 2)
 #define GA_FG_NAME lga_filter_grad_pp_x
@@ -1159,22 +1062,12 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_xp
 #define GA_FG_XP 1
 #define GA_FG_GYP 0
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 
 // gy pair-interleaved, x in the API layout (the filter gradient of the first pass of an LGA2)
 #define GA_FG_NAME lga_filter_grad_pp_gyp
@@ -1183,11 +1076,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT PC::SLOT
 #define GA_FG_NDC ND
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 // the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
 // both filter-gradient passes of an LGA2's backward in one kernel: gF(t1 pair-interleaved, gy API layout) + gF(x API layout staged
 // planar, g_t1 pair-interleaved), one write of gf (ganet_lga2_filter_grad; W % 4 == 0, 16-byte aligned volumes)
@@ -1200,16 +1088,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_FUSED
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_XP_A
-#undef GA_FG_GYP_A
-#undef GA_FG_XP_B
-#undef GA_FG_GYP_B
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 // x pair-interleaved through ONE ring per 256-thread workgroup
 #define GA_FG_NAME lga_filter_grad_pp_wxp
 #define GA_FG_XP 4
@@ -1218,12 +1096,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_fxp
 #define GA_FG_XP 4
 #define GA_FG_GYP 0
@@ -1231,12 +1103,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 // x staged planar into ONE ring per 256-thread workgroup (32 x 8 tiles; GANET_LGA_WG = 1: a barrier per pair-step, = 2: progress flags)
 #define GA_FG_NAME lga_filter_grad_pp_wx
 #define GA_FG_XP 3
@@ -1245,12 +1111,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_wgypx
 #define GA_FG_XP 3
 #define GA_FG_GYP 1
@@ -1258,12 +1118,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_fx
 #define GA_FG_XP 3
 #define GA_FG_GYP 0
@@ -1271,12 +1125,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_fgypx
 #define GA_FG_XP 3
 #define GA_FG_GYP 1
@@ -1284,23 +1132,12 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 1024
 #define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_WGSYNC
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 #define GA_FG_NAME lga_filter_grad_pp_gypx
 #define GA_FG_XP 2
 #define GA_FG_GYP 1
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
-#undef GA_FG_NAME
-#undef GA_FG_XP
-#undef GA_FG_GYP
-#undef GA_FG_SLOT
-#undef GA_FG_NDC
 
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)
