@@ -100,6 +100,9 @@ const Options &opts()
   return g_opt;
 }
 
+// (A/B only, round 5: GANET_LGA_WG=3 = the forward / data-backward on workgroup rings, the filter gradient on its one-wave kernels)
+int lga_wg_fg() { const int v = opts().lga_wg; return v == 3 ? 0 : v; }
+
 // ---- SGA kernel selection -----------------------------------------------------------
 // (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
 // GD = 64: the whole wavefront owns one scanline (D up to 1,088; 4x the waves of GD = 16 for inputs with few scanlines)
@@ -687,17 +690,17 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired && opts().lga_wg) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
+  if (x_paired && lga_wg_fg()) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
     sg.tiles_y = (H + 7) / 8;
     const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
     else GA_LAUNCH((lga_filter_grad_pp_wxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
   }
   else if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else if (GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
+  else if (GA_LGA_PLANAR && W % 4 == 0 && lga_wg_fg()) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
     sg.tiles_y = (H + 7) / 8;
     const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
     else GA_LAUNCH((lga_filter_grad_pp_wgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
   }
   else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
@@ -767,10 +770,10 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
         bool planar = false;
         if constexpr (R == 2) {
           planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
-          if (planar && opts().lga_wg) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
+          if (planar && lga_wg_fg()) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
             sg.tiles_y = (H + 7) / 8;
             const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-            if (opts().lga_wg == 2) GA_LAUNCH((lga_filter_grad_pp_fx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+            if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
             else GA_LAUNCH((lga_filter_grad_pp_wx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
             return check_launch("lga filter grad (plane pairs, workgroup ring)");
           }
@@ -861,7 +864,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value < 0 || value > 2 ? 0 : value;
+  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value < 0 || value > 3 ? 0 : value;
   else if (!strcmp(name, "GANET_SGA_POINT_Q4")) g_opt.point_q4 = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -1047,13 +1050,13 @@ GA_EXPORT int ganet_sga_backward_dir(const float *x, const float *g, const float
   return bwd_point(x, grad_x, pa, 1, N, C, D, H, W, accumulate ? 1 : 0, st);
 }
 
-GA_EXPORT int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
-                                        const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1, float *gw2,
-                                        float *gw3, int N, int C, int D, int H, int W, void *stream)
+namespace {
+// the per-pixel kernel over all four directions, with the layout of G_down / G_up DECIDED BY THE CALLER (one read of the options
+// per backward: ADVICE r4)
+int backward_point_impl(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
+                        const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1, float *gw2,
+                        float *gw3, int N, int C, int D, int H, int W, hipStream_t st, int tiled)
 {
-  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !G_ws || !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
-    return fail(GANET_E_INVALID, "ganet_sga_backward_point: null pointer");
-  GA_TRY(check_dims5("ganet_sga_backward_point", N, C, D, H, W));
   const i64 n = (i64)N * C * D * H * W;
   const float *gs[4] = {g0, g1, g2, g3};
   float *gws[4] = {gw0, gw1, gw2, gw3};
@@ -1061,7 +1064,20 @@ GA_EXPORT int ganet_sga_backward_point(const float *x, const float *g0, const fl
   for (int d = 0; d < 4; d++) {
     pa.G[d] = G_ws + d * n; pa.A[d] = A_ws + d * n; pa.g[d] = gs[d]; pa.gw[d] = gws[d]; pa.dir[d] = d;
   }
-  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, (hipStream_t)stream, sga_ws_tiled(N, C, D, H, W));
+  return bwd_point(x, grad_x, pa, 4, N, C, D, H, W, 0, st, tiled);
+}
+}  // namespace
+
+GA_EXPORT int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
+                                        const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1, float *gw2,
+                                        float *gw3, int N, int C, int D, int H, int W, void *stream)
+{
+  if (!x || !g0 || !g1 || !g2 || !g3 || !A_ws || !G_ws || !grad_x || !gw0 || !gw1 || !gw2 || !gw3)
+    return fail(GANET_E_INVALID, "ganet_sga_backward_point: null pointer");
+  GA_TRY(check_dims5("ganet_sga_backward_point", N, C, D, H, W));
+  // pairs with ganet_sga_backward_scan_ws, which keeps G_down / G_up in the layout ganet_sga_workspace_layout reports
+  return backward_point_impl(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, (hipStream_t)stream,
+                             sga_ws_tiled(N, C, D, H, W));
 }
 
 GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g1, const float *g2,
@@ -1078,12 +1094,13 @@ GA_EXPORT int ganet_sga_backward(const float *x, const float *g0, const float *g
   const i64 npix = (i64)N * C * H * W;
   hipStream_t st = (hipStream_t)stream;
   const float *gs[4] = {g0, g1, g2, g3};
-  float *gws[4] = {gw0, gw1, gw2, gw3};
-  const int tiled = sga_ws_tiled(N, C, D, H, W);
+  // The layout of G_down / G_up is private to this call: decided ONCE, from the dimensions, the options and the alignment of what
+  // the tiled column kernels touch (a contiguous but 4-byte aligned gradient takes the API layout and the generic scans).
+  const int tiled = sga_ws_tiled(N, C, D, H, W) && aligned16(g0) && aligned16(g1) && aligned16(grad_out) && aligned16(G_ws) &&
+                    (n % 4 == 0) && (((uintptr_t)mask & 3) == 0);
   for (int d = 0; d < 4; d++)
     GA_TRY(scan_bwdg(gs[d], mask, kp + d * npix, grad_out, G_ws + d * n, N, C, D, H, W, d, st, d < 2 && tiled));
-  (void)gws;
-  return ganet_sga_backward_point(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, stream);
+  return backward_point_impl(x, g0, g1, g2, g3, A_ws, G_ws, grad_x, gw0, gw1, gw2, gw3, N, C, D, H, W, st, tiled);
 }
 
 GA_EXPORT int ganet_sga_forward_compat(const float *x, const float *g0, const float *g1,

@@ -80,6 +80,24 @@ class NumpyDev:
         pass
 
 
+class _PtrAt:
+    """a device address inside a buffer that is kept alive alongside it"""
+    def __init__(self, addr, keep):
+        self.addr, self.keep = addr, keep
+
+
+class _OffsetDev:
+    """a device whose ptr() also understands _PtrAt"""
+    def __init__(self, dev):
+        self._dev = dev
+
+    def __getattr__(self, name):
+        return getattr(self._dev, name)
+
+    def ptr(self, a):
+        return a.addr if isinstance(a, _PtrAt) else self._dev.ptr(a)
+
+
 def check_sga_scan(api, dev, oracle, x, g, direction):
     N, C, D, H, W = x.shape
     dx, dg = dev.to(x), dev.to(g)
@@ -187,11 +205,17 @@ def check_sga_forward_backward(api, dev, x, gs, go, want, per_dir=True, results=
     return err
 
 
-def run_sga_backward_only(api, dev, x, gs, go):
-    """forward + backward through the composite entries, gradients as host arrays (no oracle: the caller compares runs)"""
+def run_sga_backward_only(api, dev, x, gs, go, go_offset=0):
+    """forward + backward through the composite entries, gradients as host arrays (no oracle: the caller compares runs);
+    go_offset: the incoming gradient starts that many floats into its buffer (contiguous, 4-byte aligned)"""
     N, C, D, H, W = x.shape
     dx, dg, A, out, mask, kp = run_sga_forward(api, dev, x, gs)
-    dgo = dev.to(go)
+    if go_offset:
+        dgo_buf = dev.to(np.concatenate([np.zeros(go_offset, np.float32), go.ravel()]))
+        dgo = _PtrAt(dev.ptr(dgo_buf) + 4 * go_offset, dgo_buf)
+        dev = _OffsetDev(dev)
+    else:
+        dgo = dev.to(go)
     gx = dev.empty(x.shape)
     gw = [dev.empty(gs[0].shape) for _ in range(4)]
     G = dev.empty((4,) + x.shape)

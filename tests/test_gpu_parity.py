@@ -46,6 +46,10 @@ class TorchDev:
     def sync(self):
         self.torch.cuda.synchronize()
 
+    def release(self):
+        """buffers are torch tensors: freed by reference count (the raw-hipMalloc device of test_gpu_bounds.py frees here)"""
+        self.sync()
+
 
 @pytest.fixture(scope="module")
 def api():
@@ -187,6 +191,21 @@ def test_sga_tiled_private_workspace(api, dev, port_oracle, shape, tiled):
         assert max(err.values()) <= pc.TOL, err
     finally:
         api.set_option("GANET_SGA_TILED", was)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 33, 8, 48), (1, 2, 9, 4, 16)])
+def test_sga_backward_with_a_4_byte_aligned_gradient_on_a_tiled_shape(api, dev, port_oracle, shape):
+    """where the private adjoint workspace is tiled, a contiguous gradient at a 4-byte aligned address takes the API
+    layout and the generic scans (ganet_sga_backward decides the layout once, alignment included) instead of failing."""
+    N, C, D, H, W = shape
+    assert api.query("ganet_sga_workspace_layout", N, C, D, H, W) == 1
+    x, gs, go = pc.sga_inputs(shape, seed=11)
+    got = pc.run_sga_backward_only(api, dev, x, gs, go, go_offset=1)
+    out, tmp, mask = port_oracle.sga_forward(x, *gs)
+    grads = port_oracle.sga_backward(x, *gs, tmp, mask, go)
+    assert np.abs(got["gx"] - grads[0]).max() <= pc.TOL
+    for d in range(4):
+        assert np.abs(got[f"gw{d}"] - grads[1 + d]).max() <= pc.TOL
 
 
 def test_full_size_properties(api, dev):

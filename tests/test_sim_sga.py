@@ -186,6 +186,22 @@ def test_tiled_private_workspace(sim, port_oracle, shape, tiled):
         sim.set_option("GANET_SGA_TILED", was)
 
 
+def test_backward_with_a_4_byte_aligned_gradient_on_a_tiled_shape(sim, port_oracle):
+    """on a shape where the private adjoint workspace is tiled (W % 16 == 0, H % 4 == 0), a gradient that is contiguous
+    but only 4-byte aligned must take the API layout and the generic scans, not fail: ganet_sga_backward decides the layout
+    once, from the dimensions, the options AND the alignment of what the tiled kernels would touch."""
+    shape = (1, 1, 5, 4, 16)
+    N, C, D, H, W = shape
+    assert sim.query("ganet_sga_workspace_layout", N, C, D, H, W) == 1
+    x, gs, go = pc.sga_inputs(shape, seed=3)
+    got = pc.run_sga_backward_only(sim, pc.NumpyDev("end"), x, gs, go, go_offset=1)
+    out, tmp, mask = port_oracle.sga_forward(x, *gs)
+    grads = port_oracle.sga_backward(x, *gs, tmp, mask, go)
+    assert np.abs(got["gx"] - grads[0]).max() <= pc.TOL
+    for d in range(4):
+        assert np.abs(got[f"gw{d}"] - grads[1 + d]).max() <= pc.TOL
+
+
 def test_tiled_workspace_falls_back_where_it_does_not_apply(sim, port_oracle):
     """W % 16 != 0 or H % 4 != 0: the workspace keeps the API layout whatever the option says."""
     was = sim.get_option("GANET_SGA_TILED")
