@@ -145,12 +145,6 @@ def stage_timings(inp, iters=5, only=None):
         ("lga_bwd_filter_grad_1", lambda: lib.call("ganet_lga_filter_grad_paired", p(xl), p(gtp), p(gf), B, DL, HL, WL, RADIUS, 1, 0, 1, st)),
         ("lga_bwd_data_1", lambda: lib.call("ganet_lga_apply_paired_edges", p(gtp), p(f), p(gxl), p(edge), B, DL, HL, WL, RADIUS, 1, 1, 0, st)),
     ]
-    if os.environ.get("GANET_LGA_FG_FUSED", "0") == "1" and WL % 4 == 0:
-        # what Lga2Function.backward issues with that switch: the first data-backward, then BOTH filter-gradient passes in one launch
-        calls = [c for c in calls if not c[0].startswith("lga_bwd_filter_grad")]
-        i = next(k for k, c in enumerate(calls) if c[0] == "lga_bwd_data_2") + 1
-        calls.insert(i, ("lga_bwd_filter_grad_fused", lambda: lib.call("ganet_lga2_filter_grad", p(tp), p(gy), p(xl), p(gtp), p(gf),
-                                                                    B, DL, HL, WL, RADIUS, 0, st)))
     if only is not None:          # (development A/B scripts: one op's kernels, e.g. with a library build that lacks the newer entries)
         calls = [c for c in calls if c[0].startswith(only)]
     for _ in range(2):
@@ -185,13 +179,13 @@ _FAMILY_KERNELS = {
     "sga_bwd_scan": [["sga_col_bwdg<5, false, true, true>"], ["sga_col_bwdg<5, true, true, true>"],
                      ["sga_row_bwdg<2, 32, 4, 1, true, false, 64, 9>"], ["sga_row_bwdg<2, 32, 4, 1, false, false, 64, 9>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false, true>|sga_bwd_point<4, false>|sga_bwd_point<4, false, false>"]],   # (a|b: first name found)
-    # (the workgroup-ring forms of GANET_LGA_WG = 1 | 2 as alternatives: whichever the traffic file of the measured tree holds)
-    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_xp<2, 3, 0>|lga_filter_grad_pp_wxp<2, 3, 0>|lga_filter_grad_pp_fxp<2, 3, 0>",
-                                          "lga_apply_pp_xo<2, true, false>|lga_apply_pp_wxo<2, true, false>|lga_apply_pp_fxo<2, true, false>"],
-                                         ["lga_filter_grad_pp_gypx<2, 3, 0>|lga_filter_grad_pp_wgypx<2, 3, 0>|lga_filter_grad_pp_fgypx<2, 3, 0>",
-                                          "lga_apply_pp_pi<2, true, false>|lga_apply_pp_wpi<2, true, false>|lga_apply_pp_fpi<2, true, false>"]],
-    "lga_apply (fwd pass)": [["lga_apply_pp_xo<2, false, false>|lga_apply_pp_wxo<2, false, false>|lga_apply_pp_fxo<2, false, false>"],
-                             ["lga_apply_pp_pi<2, false, false>|lga_apply_pp_wpi<2, false, false>|lga_apply_pp_fpi<2, false, false>"]],
+    # (workgroup-ring kernels = the default, GANET_LGA_WG=1; the one-wave names as alternatives: whichever the traffic file holds)
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_wxp<2, 3, 0>|lga_filter_grad_pp_xp<2, 3, 0>",
+                                          "lga_apply_pp_wxo<2, true, false>|lga_apply_pp_xo<2, true, false>"],
+                                         ["lga_filter_grad_pp_wgypx<2, 3, 0>|lga_filter_grad_pp_gypx<2, 3, 0>",
+                                          "lga_apply_pp_wpi<2, true, false>|lga_apply_pp_pi<2, true, false>"]],
+    "lga_apply (fwd pass)": [["lga_apply_pp_wxo<2, false, false>|lga_apply_pp_xo<2, false, false>"],
+                             ["lga_apply_pp_wpi<2, false, false>|lga_apply_pp_pi<2, false, false>"]],
 }
 
 
@@ -207,10 +201,36 @@ ACHIEVABLE = {"hbm_copy_GBs": 6300.0, "hbm_4in_1out_marching_GBs": 5000.0, "hbm_
 # either): the kernels use the packed VALU and no MFMA instruction, so MFMA utilisation is 0 by construction.
 MFMA_NOTE = {"used": False, "mfma_utilisation": 0.0, "fp32_mfma_peak_TFLOPs": FP32_PEAK_TFLOPS,
              "f32_4x4x1_measured_TFLOPs": [77.0, 90.0], "pk_fma_measured_TFLOPs": 134.0,
-             "why": "per-pixel [D x 25].[25 x 3]: N = 3 of an MFMA tile's 16/32 columns; packed fp32 VALU is the faster unit",
+             "why": "per-pixel [D x 25].[25 x 3]: N = 3 of an MFMA tile's 16/32 columns; packed fp32 VALU is the faster unit.  Only "
+                    "v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 blocks: N = 3 of 4) was timed; the 16x16x4 / 32x32x2 f32 shapes reach "
+                    "155 TFLOP/s per MI355X_MICROARCH.md but at N = 3 of 16 / 32 columns deliver <= 19 % / <= 9 % of that as useful "
+                    "flops (<= 29 TFLOP/s against the 47 the packed VALU kernels run at), so they were not built",
              "source": "profiles/r2a_ubench_valu_rate.txt, DESIGN.md section 3.3"}
 _LGA_PASS_FLOPS = 2.0 * 75 * 193 * 240 * 624      # 75 FMAs per output element, one apply or one filter-gradient pass
 _FAMILY_FLOPS = {"lga_apply (fwd pass)": _LGA_PASS_FLOPS, "lga_apply+filter_grad (bwd pass)": 2 * _LGA_PASS_FLOPS}
+
+
+def csrc_tree_hash():
+    """sha256[:12] over the kernel sources (ganet_amd/csrc/*.hip|*.h|*.inc, names and contents, sorted): identifies the tree a
+    traffic file was measured on (scripts/pmc_traffic.py stores it; bench warns when the file describes other kernels)."""
+    import hashlib
+    d = os.path.join(ROOT, "ganet_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            h.update(fn.encode())
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic_tree():
+    """the csrc hash profiles/traffic_pmc.json was generated on (None: an older file / no file)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
+            return json.load(f).get("csrc_tree")
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic():
@@ -305,6 +325,15 @@ def roofline_from_stages(stages):
                      "the step's 16 launches): stage_ms; no family is a difference of other measurements")
     out["mfma"] = MFMA_NOTE
     out["achievable"] = ACHIEVABLE
+    # which kernels the traffic figures describe: the file is made in a profiler session of its own (counters cannot be collected
+    # inside the timed run), so it names the tree it was measured on and a mismatch is said out loud
+    out["traffic_tree"] = pmc_traffic_tree()
+    out["csrc_tree"] = csrc_tree_hash()
+    out["traffic_tree_matches"] = out["traffic_tree"] == out["csrc_tree"]
+    if kern is not None and not out["traffic_tree_matches"]:
+        print(f"[bench] WARNING: profiles/traffic_pmc.json was measured on csrc tree {out['traffic_tree']}, this tree is "
+              f"{out['csrc_tree']}: roofline.traffic / unit_traffic_ratio may describe other kernels "
+              "(regenerate: scripts/gpu_session.sh <tag> pmc)", file=sys.stderr, flush=True)
     return out
 
 
@@ -482,6 +511,13 @@ def main():
         # (scripts/diag_bench_timing.py, profiles/r7k_diag_bench_timing.txt).  W = 5 warm-up steps are 8 ms, so the device is
         # brought back to its running state first (replays for SETTLE_S seconds, reported in the line); then the W warm-up
         # steps and the K timed ones as the contract has them.
+        # The contract's protocol as it stands -- W warm-up steps and K timed ones straight after the capture -- is measured first and
+        # reported as `value_no_settle`, so the protocol's effect on `value` stays visible (rounds 1-3 reported this quantity).
+        for _ in range(args.warmup):
+            graph.replay()
+        elapsed_ns = gdist.timed_region(ctx, lambda: [graph.replay() for _ in range(args.steps)],
+                                        sync=torch.cuda.synchronize)
+        value_no_settle = ctx.world_size * args.steps / elapsed_ns
         t_settle = time.perf_counter()
         while time.perf_counter() - t_settle < SETTLE_S:
             for _ in range(10):
@@ -496,6 +532,7 @@ def main():
             one_step(inp)
         elapsed = gdist.timed_region(ctx, lambda: [one_step(inp) for _ in range(args.steps)],
                                      sync=torch.cuda.synchronize)
+        value_no_settle = None
     value = ctx.world_size * args.steps / elapsed
     if graph is not None:
         value_1s, n_blocks = sustained_rate(ctx, lambda: [graph.replay() for _ in range(args.steps)], args.steps)
@@ -508,6 +545,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "value_1s": round(value_1s, 2), "value_1s_blocks": n_blocks,
+        "value_no_settle": round(value_no_settle, 2) if value_no_settle is not None else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: SGA fwd+bwd [1,32,65,80,208] (4x guidance [1,32,5,80,208]) + "

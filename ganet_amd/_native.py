@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -42,7 +42,6 @@ _PROTOS = {
     "ganet_lga_apply_paired": [_P] * 3 + [_I] * 8 + [_P],
     "ganet_lga_apply_paired_edges": [_P] * 4 + [_I] * 8 + [_P],
     "ganet_lga_filter_grad_paired": [_P] * 3 + [_I] * 8 + [_P],
-    "ganet_lga2_filter_grad": [_P] * 5 + [_I] * 6 + [_P],
     "ganet_cost_volume_forward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_cost_volume_backward": [_P] * 3 + [_I] * 5 + [_P],
     "ganet_disparity_regression_forward": [_P] * 2 + [_I] * 4 + [_P],

@@ -13,8 +13,6 @@ SOURCES = {
     # everything else is a few per cent faster with it
     "sga_row_tu.hip": ["-fno-slp-vectorize"],
 }
-HEADERS = ["ga_common.h", "ga_launch.h", "sga_kernels.h", "sga_row_kernels.h", "sga_col_kernels.h", "sga_col_kernels.inc", "lga_kernels.h", "lga_apply_pp.inc", "lga_filter_grad_pp.inc",
-           "misc_kernels.h"]
 LIB_SONAME = "libganet_hip.so"
 OUT = os.path.join(_HERE, LIB_SONAME)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
@@ -30,7 +28,8 @@ def _stale(out, deps):
 def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> libganet_hip.so.  hipcc cross-compiles without a GPU."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    deps = [os.path.join(CSRC, f) for f in list(SOURCES) + HEADERS]
+    # every file under csrc/ (sources, headers, textually included kernels): a new include cannot be forgotten here
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     deps += [os.path.join(os.path.dirname(_HERE), "include", "ganet_hip.h"), os.path.abspath(__file__)]
     if not force and not _stale(out, deps):
         return out

@@ -61,11 +61,7 @@ GA_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 #define GA_OPAQUE_V(v) asm volatile("" : "+v"(v))   // the same for a per-lane value
 #define GA_OPAQUE_VF(v) asm("" : "+v"(v))          // ... without `volatile`: only hides where the value came from (may be moved, dropped if unused)
 // nothing is scheduled across this point: used to pin a hand-chosen instruction interleaving
-#if defined(GA_NO_SCHED_FENCE)
-#define GA_SCHED_FENCE() ((void)0)
-#else
 #define GA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 #endif
 // one 8-byte LDS read that stays a ds_read_b64 (256 B/clk/CU): left alone, the compiler fuses
 // neighbouring pairs into ds_read2_b64, which the LDS serves at half that rate

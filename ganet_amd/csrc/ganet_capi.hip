@@ -65,8 +65,7 @@ struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
-  std::atomic<int> point_q4{0};     // SGA per-pixel gradient kernel with four pixels of ONE direction per lane (sga_bwd_point_q4: 16-byte loads, same per-lane state); built in round 4 after the last GPU minute, not yet measured: off
-  std::atomic<int> lga_wg{0};       // plane-pair LGA kernels (forward / data-backward and filter gradient, API-layout and pair-interleaved operands): ONE x ring per 256-thread workgroup on 32 x 8 tiles instead of one per wave -- 1: a workgroup barrier per plane pair (lga_apply_pp_w*, lga_filter_grad_pp_w*), 2: progress flags in LDS, the waves within LGAP_WG_SLACK pairs of each other (lga_apply_pp_f*, lga_filter_grad_pp_f*); built and emulator-verified in round 4, not yet measured: off
+  std::atomic<int> lga_wg{1};       // plane-pair LGA kernels (forward / data-backward and filter gradient, API-layout and pair-interleaved operands): 1 ONE x ring per 256-thread workgroup on 32 x 8 tiles, a workgroup barrier per plane pair (lga_apply_pp_w*, lga_filter_grad_pp_w*; measured: whole step -4.4 %, profiles/r8b_*), 0 one ring per wave on 32 x 2 tiles (the fallback; also taken where W % 4 != 0)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -88,7 +87,6 @@ void load_env_options()
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
   geti("GANET_LGA_WG", g_opt.lga_wg);
-  geti("GANET_SGA_POINT_Q4", g_opt.point_q4);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
@@ -99,9 +97,6 @@ const Options &opts()
   std::call_once(g_opt_once, load_env_options);
   return g_opt;
 }
-
-// (A/B only, round 5: GANET_LGA_WG=3 = the forward / data-backward on workgroup rings, the filter gradient on its one-wave kernels)
-int lga_wg_fg() { const int v = opts().lga_wg; return v == 3 ? 0 : v; }
 
 // ---- SGA kernel selection -----------------------------------------------------------
 // (lanes per scanline GD, disparities per lane DPL) pairs compiled in.
@@ -483,23 +478,6 @@ int bwd_point(const float *x, float *gx, const PointArgs &pa, int ndir, int N, i
   const i64 gmax = (i64)256 * 32 * (256 / pb);
   if (gsz > gmax) gsz = gmax;
   if (gsz < 1) gsz = 1;
-  if (ndir == 4 && opts().point_q4 && W % 4 == 0) {      // four pixels of one direction per lane: 16-byte loads (not measured yet: off)
-    // (32-bit byte offsets inside the kernel: a volume, and the directions' volumes measured from direction 0's, below 4 GB)
-    const i64 vbytes = 4 * npix * D;
-    bool al = aligned16(x) && aligned16(gx) && vbytes < (1ll << 32);
-    for (int q = 0; q < 4; q++) {
-      const i64 dg = (const char *)pa.G[q] - (const char *)pa.G[0], da = (const char *)pa.A[q] - (const char *)pa.A[0];
-      al = al && aligned16(pa.G[q]) && aligned16(pa.A[q]) && aligned16(pa.g[q]) && aligned16(pa.gw[q]) && pa.dir[q] == q &&
-           dg >= 0 && da >= 0 && dg + vbytes < (1ll << 32) && da + vbytes < (1ll << 32);
-    }
-    if (al) {
-      if (accumulate && tiled) GA_LAUNCH((sga_bwd_point_q4<true, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-      else if (accumulate) GA_LAUNCH((sga_bwd_point_q4<true, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-      else if (tiled) GA_LAUNCH((sga_bwd_point_q4<false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-      else GA_LAUNCH((sga_bwd_point_q4<false, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
-      return check_launch("sga per-pixel gradients (pixel quads)");
-    }
-  }
   if (ndir == 4 && !accumulate && tiled) GA_LAUNCH((sga_bwd_point<4, false, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4 && accumulate) GA_LAUNCH((sga_bwd_point<4, true>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
   else if (ndir == 4) GA_LAUNCH((sga_bwd_point<4, false>), dim3((unsigned)gsz), dim3(pb), st, x, gx, pa, D, H, W, npix);
@@ -601,10 +579,7 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
         if (planar && opts().lga_wg) {                      // one ring per 256-thread workgroup (32 x 8 tiles)
           const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
           if (items < (1ll << 31)) {
-            const bool flags = opts().lga_wg == 2;          // progress flags instead of a barrier per pair-step
-            if (flags && transposed) GA_LAUNCH((lga_apply_pp_fx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
-            else if (flags) GA_LAUNCH((lga_apply_pp_fx<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
-            else if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
+            if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
             else GA_LAUNCH((lga_apply_pp_wx<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
             return check_launch("lga apply (plane pairs, workgroup ring)");
           }
@@ -644,10 +619,7 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   if (x_paired && opts().lga_wg) {                                       // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
-      const bool flags = opts().lga_wg == 2;                // progress flags instead of a barrier per pair-step
-      if (flags && transposed) GA_LAUNCH((lga_apply_pp_fpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
-      else if (flags) GA_LAUNCH((lga_apply_pp_fpi<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
-      else if (transposed) GA_LAUNCH((lga_apply_pp_wpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      if (transposed) GA_LAUNCH((lga_apply_pp_wpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       else GA_LAUNCH((lga_apply_pp_wpi<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       return check_launch("lga apply (plane pairs, interleaved input, workgroup ring)");
     }
@@ -655,10 +627,7 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
-      const bool flags = opts().lga_wg == 2;                // progress flags instead of a barrier per pair-step
-      if (flags && transposed) GA_LAUNCH((lga_apply_pp_fxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
-      else if (flags) GA_LAUNCH((lga_apply_pp_fxo<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
-      else if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
+      if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       else GA_LAUNCH((lga_apply_pp_wxo<2, false>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
       return check_launch("lga apply (plane pairs, interleaved volume, workgroup ring)");
     }
@@ -690,41 +659,20 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired && lga_wg_fg()) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
+  if (x_paired && opts().lga_wg) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
     sg.tiles_y = (H + 7) / 8;
     const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-    else GA_LAUNCH((lga_filter_grad_pp_wxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    GA_LAUNCH((lga_filter_grad_pp_wxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
   }
   else if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else if (GA_LGA_PLANAR && W % 4 == 0 && lga_wg_fg()) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
+  else if (GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
     sg.tiles_y = (H + 7) / 8;
     const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-    else GA_LAUNCH((lga_filter_grad_pp_wgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+    GA_LAUNCH((lga_filter_grad_pp_wgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
   }
   else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
-}
-
-// both filter-gradient passes of an LGA2's backward in one launch (lga_filter_grad_pp_lga2): gf (=|+=) gF(t1p, gy) + gF(x, gt1p)
-int launch_lga2_gf(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D, int H, int W,
-                   int acc, hipStream_t st)
-{
-  if ((i64)H * W >= (1ll << 28) || W % 4 != 0 || !GA_LGA_PLANAR || !aligned16(t1p) || !aligned16(gy) || !aligned16(x) || !aligned16(gt1p))
-    return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: needs W % 4 == 0, planes below 2^28 pixels and 16-byte aligned volumes "
-                                     "(otherwise: two ganet_lga_filter_grad_paired calls)");
-  LgaGeom geo;
-  geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
-  LgaSeg sg;
-  sg.tiles_x = (W + LGA_TW - 1) / LGA_TW;
-  sg.tiles_y = (H + LGAW_TH - 1) / LGAW_TH;
-  sg.nseg = 1; sg.seg_len = D;
-  const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
-  if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: too many tiles");
-  GA_LAUNCH((lga_filter_grad_pp_lga2<2, 3, 0>), dim3((unsigned)items), dim3(64), st, t1p, gy, x, gt1p, gf, geo, sg, acc);
-  return check_launch("lga2 filter grad (both passes, plane pairs)");
 }
 
 // one LGA pass whose output is also reduced over d per pixel (plane-pair kernel, one depth segment per tile)
@@ -770,11 +718,10 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
         bool planar = false;
         if constexpr (R == 2) {
           planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
-          if (planar && lga_wg_fg()) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
+          if (planar && opts().lga_wg) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
             sg.tiles_y = (H + 7) / 8;
             const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-            if (lga_wg_fg() == 2) GA_LAUNCH((lga_filter_grad_pp_fx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-            else GA_LAUNCH((lga_filter_grad_pp_wx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
+            GA_LAUNCH((lga_filter_grad_pp_wx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
             return check_launch("lga filter grad (plane pairs, workgroup ring)");
           }
           if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
@@ -847,7 +794,6 @@ GA_EXPORT int ganet_get_option(const char *name)
   if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
   if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
   if (!strcmp(name, "GANET_LGA_WG")) return g_opt.lga_wg;
-  if (!strcmp(name, "GANET_SGA_POINT_Q4")) return g_opt.point_q4;
   if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
   if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
   if (!strcmp(name, "GANET_SGA_WIDE_COL")) return g_opt.wide_col;
@@ -864,8 +810,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value < 0 || value > 3 ? 0 : value;
-  else if (!strcmp(name, "GANET_SGA_POINT_Q4")) g_opt.point_q4 = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
@@ -873,7 +818,6 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
   else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;
-  else if (!strcmp(name, "HIPSIM_FLAG_SLACK")) hipsim::S().flag_slack = value;     // tests: progress-flag polls loosened by `value` steps
   else if (!strcmp(name, "HIPSIM_WAVE_GREEDY")) hipsim::S().wave_greedy = value ? 1 : 0;   // one wavefront runs as far as its synchronisation lets it
   else if (!strcmp(name, "HIPSIM_LATE_LDS")) hipsim::S().late_lds = value != 0;
   else if (!strcmp(name, "HIPSIM_LGKM_SLACK")) hipsim::S().lgkm_slack = value;     // tests: every counted LDS wait loosened by `value`
@@ -1209,15 +1153,6 @@ GA_EXPORT int ganet_lga_filter_grad_paired(const float *x, const float *gy, floa
   if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: radius 2 only");
   if (!x_paired && !gy_paired) return launch_lga_gf<2>(x, gy, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
   return launch_lga_gf_paired(x, gy, gf, B, D, H, W, accumulate_gf != 0, x_paired != 0, (hipStream_t)stream);
-}
-
-GA_EXPORT int ganet_lga2_filter_grad(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D,
-                                     int H, int W, int radius, int accumulate_gf, void *stream)
-{
-  if (!t1p || !gy || !x || !gt1p || !gf) return fail(GANET_E_INVALID, "ganet_lga2_filter_grad: null pointer");
-  GA_TRY(check_lga("ganet_lga2_filter_grad", B, D, H, W, radius));
-  if (radius != 2) return fail(GANET_E_UNSUPPORTED, "ganet_lga2_filter_grad: radius 2 only");
-  return launch_lga2_gf(t1p, gy, x, gt1p, gf, B, D, H, W, accumulate_gf != 0, (hipStream_t)stream);
 }
 
 GA_EXPORT int ganet_lga_forward_regress(const float *x, const float *f, float *y, float *snorm, float *sdy, int B, int D,

@@ -390,9 +390,6 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_NR
 #define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
 #endif
-#ifndef LGAP_WG_SLACK
-#define LGAP_WG_SLACK 1   // flag-synchronised workgroup ring: pair-steps a wave may be ahead of the slowest wave of its workgroup
-#endif
 #ifndef LGAP_WG_NR_FG
 #define LGAP_WG_NR_FG LGAP_WG_NR      // the filter gradient's x ring (its steady groups are NR steps long: at D = 193, 8 slots leave 17 of 97 steps to the general body, 6 leave 13)
 #endif
@@ -401,9 +398,6 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #endif
 #ifndef LGAP_ROW_ASM
 #define LGAP_ROW_ASM 1           // radius 2: a window row's 15 packed FMAs as one asm statement (lga_row_fma); 0 = one statement per FMA
-#endif
-#ifndef LGAP_ABLATE
-#define LGAP_ABLATE 0            // development only (steady body of lga_apply_pp): bit 0 no copies, 1 no y stores, 2 no LDS reads, 3 no FMAs, 4 no tap gather
 #endif
 // Two dwords of one LDS row pair in ONE instruction, into a register pair: p[O0] and p[O1] (dword offsets, at most 255).  The
 // planar staging of lga_apply_pp.inc (GA_PP_IN = 2) keeps the two planes of a pair LGA_TW + 8 dwords apart; written as two
@@ -759,63 +753,6 @@ GA_DEV void lga_dma16p_one(const float *base, unsigned off, float *slot, int lan
 #endif
 }
 
-// ---- progress flags of the workgroup-shared ring (lga_apply_pp.inc, GA_PP_IN = 3 with GA_PP_WGSYNC = 1) ----------------------
-// prog[w] = the pair-step wave w has reached.  A wave publishes its step after its own copies have landed (and, program order
-// of its LDS queue, after its reads of the slot it lets go), then needs every wave to be within `slack` steps of it.  Both
-// accesses are plain LDS operations on an address_space(3) pointer: a generic pointer would make them FLAT operations, which
-// count in vmcnt as well and would break the march's hand-counted waits.
-#if defined(GA_HIPSIM)
-typedef int *lds_iptr;
-#define GA_LDS_IPTR(p) (p)
-GA_DEV void lga_wg_publish(lds_iptr prog, int wv, int step)
-{
-  GA_WAVE_SYNC();                                  // (emulator: EVERY lane of the wave has made its wait; lockstep on the device)
-  if (hipsim::lane_id() == 0) prog[wv] = step;
-}
-GA_DEV void lga_wg_wait(lds_iptr prog, int need)
-{
-  for (;;) {
-    int m = prog[0];
-    for (int k = 1; k < 4; k++) m = prog[k] < m ? prog[k] : m;
-    if (m >= need - hipsim::S().flag_slack) break;      // (flag_slack: tests -- a poll that is too permissive must fail)
-    hipsim::yield();
-  }
-}
-struct LgaWgFlag { lds_iptr prog; int wv; };
-GA_DEV LgaWgFlag lga_wg_flag_addr(lds_iptr prog, int wv) { return LgaWgFlag{prog, wv}; }
-GA_DEV void lga_wg_step(LgaWgFlag fl, int step, int need) { lga_wg_publish(fl.prog, fl.wv, step); lga_wg_wait(fl.prog, need); }
-#else
-typedef __attribute__((address_space(3))) int *lds_iptr;
-#define GA_LDS_IPTR(p) ((ga::lds_iptr)(p))
-// the lane's flag address for both operations: lane l polls the flag of wave (l + wv) % 4, so lane 0's is the wave's own
-GA_DEV unsigned lga_wg_flag_addr(lds_iptr prog, int wv) { return (unsigned)(size_t)prog + 4u * ((unsigned)(lane_id() + wv) & 3u); }
-// publish `step`, then wait until no flag is below `need` (<= step): one statement, nine instructions on the way through --
-// one lane writes (EXEC is all ones here: uniform control flow of a full wave), every lane reads one of the four flags, and
-// the wave goes on when the comparison is false in all of them
-GA_DEV void lga_wg_step(unsigned flag_addr, int step, int need)
-{
-  int t;
-  asm volatile("v_mov_b32 %0, %2\n\t"
-               "s_mov_b64 exec, 1\n\t"
-               "ds_write_b32 %1, %0\n\t"
-               "s_mov_b64 exec, -1\n"
-               "1:\n\t"
-               "ds_read_b32 %0, %1\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               "v_cmp_gt_i32 vcc, %3, %0\n\t"
-               "s_cbranch_vccz 2f\n\t"
-               "s_sleep 1\n\t"
-               "s_branch 1b\n"
-               "2:"
-               : "=&v"(t) : "v"(flag_addr), "s"(step), "s"(need) : "vcc", "memory");
-}
-GA_DEV void lga_wg_publish(lds_iptr prog, int wv, int step)
-{
-  const unsigned addr = (unsigned)(size_t)(prog + wv);
-  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" : : "v"(addr), "v"(step) : "memory");
-}
-#endif
-
 // ---- item list of the forward / data-backward kernels: whole tiles first, then tiles cut into depth segments -----------------
 // These kernels are bound by VALU issue and the waves of a SIMD share one VALU, so a pass lasts as long as the SIMD with the
 // most resident work: 2,400 tiles on 1,024 SIMDs are 2 or 3 tiles per SIMD and the pass takes the time of 3 (the FMA-only
@@ -870,17 +807,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
 
-// ... the waves kept within LGAP_WG_SLACK pair-steps of each other by progress flags in LDS instead of a barrier per step (GANET_LGA_WG=2)
-#define GA_PP_NAME lga_apply_pp_fx
-#define GA_PP_SEG_T LgaSegMix
-#define GA_PP_DECODE lga_decode_item_mix
-#define GA_PP_IN 3
-#define GA_PP_WGSYNC 1
-#define GA_PP_OUT 0
-#define GA_PP_SLOT 1024
-#define GA_PP_NDC 1
-#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
-#include "lga_apply_pp.inc"
 
 // API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WG)
 #define GA_PP_NAME lga_apply_pp_wx
@@ -914,17 +840,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
-// ... the waves kept within LGAP_WG_SLACK pair-steps of each other by progress flags in LDS instead of a barrier per step (GANET_LGA_WG=2)
-#define GA_PP_NAME lga_apply_pp_fxo
-#define GA_PP_SEG_T LgaSegMix
-#define GA_PP_DECODE lga_decode_item_mix
-#define GA_PP_IN 3
-#define GA_PP_WGSYNC 1
-#define GA_PP_OUT 1
-#define GA_PP_SLOT 1024
-#define GA_PP_NDC 1
-#define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
-#include "lga_apply_pp.inc"
 
 // the same with ONE planar ring per 256-thread workgroup (GANET_LGA_WG)
 #define GA_PP_NAME lga_apply_pp_wxo
@@ -946,22 +861,11 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-// the same through ONE ring per 256-thread workgroup (GANET_LGA_WG = 1: barrier per pair-step, = 2: progress flags)
+// the same through ONE ring per 256-thread workgroup (GANET_LGA_WG)
 #define GA_PP_NAME lga_apply_pp_wpi
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
 #define GA_PP_IN 4
-#define GA_PP_WGSYNC 0
-#define GA_PP_OUT 0
-#define GA_PP_SLOT 1024
-#define GA_PP_NDC 1
-#define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
-#include "lga_apply_pp.inc"
-#define GA_PP_NAME lga_apply_pp_fpi
-#define GA_PP_SEG_T LgaSegMix
-#define GA_PP_DECODE lga_decode_item_mix
-#define GA_PP_IN 4
-#define GA_PP_WGSYNC 1
 #define GA_PP_OUT 0
 #define GA_PP_SLOT 1024
 #define GA_PP_NDC 1
@@ -1054,7 +958,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT PC::SLOT
 #define GA_FG_NDC ND
 #include "lga_filter_grad_pp.inc"
-// x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
 // x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x; radius 2)
 #define GA_FG_NAME lga_filter_grad_pp_x
 #define GA_FG_XP 2
@@ -1062,6 +965,7 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
+// x pair-interleaved (the filter gradient of the second pass of an LGA2, whose x is the private intermediate)
 #define GA_FG_NAME lga_filter_grad_pp_xp
 #define GA_FG_XP 1
 #define GA_FG_GYP 0
@@ -1077,66 +981,33 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_NDC ND
 #include "lga_filter_grad_pp.inc"
 // the same with the API-layout x staged planar by 16-byte copies (W % 4 == 0, 16-byte aligned x)
-// both filter-gradient passes of an LGA2's backward in one kernel: gF(t1 pair-interleaved, gy API layout) + gF(x API layout staged
-// planar, g_t1 pair-interleaved), one write of gf (ganet_lga2_filter_grad; W % 4 == 0, 16-byte aligned volumes)
-#define GA_FG_NAME lga_filter_grad_pp_lga2
-#define GA_FG_FUSED 1
-#define GA_FG_XP_A 1
-#define GA_FG_GYP_A 0
-#define GA_FG_XP_B 2
-#define GA_FG_GYP_B 1
-#define GA_FG_SLOT 512
-#define GA_FG_NDC 2
-#include "lga_filter_grad_pp.inc"
-// x pair-interleaved through ONE ring per 256-thread workgroup
-#define GA_FG_NAME lga_filter_grad_pp_wxp
-#define GA_FG_XP 4
-#define GA_FG_GYP 0
-#define GA_FG_WGSYNC 0
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-#define GA_FG_NAME lga_filter_grad_pp_fxp
-#define GA_FG_XP 4
-#define GA_FG_GYP 0
-#define GA_FG_WGSYNC 1
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-// x staged planar into ONE ring per 256-thread workgroup (32 x 8 tiles; GANET_LGA_WG = 1: a barrier per pair-step, = 2: progress flags)
-#define GA_FG_NAME lga_filter_grad_pp_wx
-#define GA_FG_XP 3
-#define GA_FG_GYP 0
-#define GA_FG_WGSYNC 0
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-#define GA_FG_NAME lga_filter_grad_pp_wgypx
-#define GA_FG_XP 3
-#define GA_FG_GYP 1
-#define GA_FG_WGSYNC 0
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-#define GA_FG_NAME lga_filter_grad_pp_fx
-#define GA_FG_XP 3
-#define GA_FG_GYP 0
-#define GA_FG_WGSYNC 1
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-#define GA_FG_NAME lga_filter_grad_pp_fgypx
-#define GA_FG_XP 3
-#define GA_FG_GYP 1
-#define GA_FG_WGSYNC 1
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
 #define GA_FG_NAME lga_filter_grad_pp_gypx
 #define GA_FG_XP 2
 #define GA_FG_GYP 1
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
+#include "lga_filter_grad_pp.inc"
+
+// x through ONE ring per 256-thread workgroup (32 x 8 tiles, a barrier per pair-step; GANET_LGA_WG): pair-interleaved x,
+#define GA_FG_NAME lga_filter_grad_pp_wxp
+#define GA_FG_XP 4
+#define GA_FG_GYP 0
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+// API-layout x staged planar,
+#define GA_FG_NAME lga_filter_grad_pp_wx
+#define GA_FG_XP 3
+#define GA_FG_GYP 0
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
+#include "lga_filter_grad_pp.inc"
+// and the same with gy pair-interleaved
+#define GA_FG_NAME lga_filter_grad_pp_wgypx
+#define GA_FG_XP 3
+#define GA_FG_GYP 1
+#define GA_FG_SLOT 1024
+#define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
 
 // ---- filter backward --------------------------------------------------------------

@@ -33,10 +33,6 @@
 #pragma once
 #include "ga_common.h"
 
-#ifndef GA_SCAN_ABLATE
-#define GA_SCAN_ABLATE 0     // A/B builds only (scripts/build_variants.py): 1 = the tile path of the LDS-staged scans without the recurrence
-#endif
-
 namespace ga {
 
 // One traversal over [S slices][D][H][W] (+ guidance [S][5][H][W]), in VISIT order
@@ -648,155 +644,6 @@ sga_bwd_point(const float *__restrict__ x, float *__restrict__ gradX, PointArgs 
       gw[3 * HW] = hp ? s3[q] : 0.f;
       gw[4 * HW] = hp ? sg[q] * mx[q] : 0.f;
     }
-  }
-}
-
-// ---- the same per-pixel gradients, FOUR consecutive pixels of ONE direction per lane -----------------------------------------
-// Lane l of a wave: pixel quad l / 4 (16 quads = the same 64 consecutive pixels a wave of sga_bwd_point covers), direction l % 4.
-// What changes is the shape of the memory instructions: per plane a lane issues ONE 16-byte load of its direction's adjoint
-// volume, ONE 16-byte load of its forward volume at the previous scan position (+ one dword for the horizontal directions, whose
-// previous position is a column off: the quad is loaded aligned and shifted in registers) and one dword of x -- 4 loads instead
-// of 9, two of them 16 bytes wide (the merge kernel went from 4.4 to 6 TB/s on that change, sga_merge_px4) -- with the per-lane
-// state unchanged (one direction x four pixels instead of four directions x one pixel: the two-pixels-per-lane form of round 4
-// lost because its state doubled).  x is shared inside the quad by DPP broadcasts, the four directions' contributions to gradX
-// are summed across the quad's lanes by two DPP adds per pixel, the quad's first lane stores the four sums.  W % 4 == 0, 16-byte aligned volumes, the
-// four-direction launch only (direction q in slot q).
-#ifndef GA_POINT_Q4_WAVES
-#define GA_POINT_Q4_WAVES 4      // at five waves per SIMD (96 VGPRs) the kernel spills 8 - 16 registers around its plane loop; 4 and 5 measured equal for sga_bwd_point (profiles/r4a_*)
-#endif
-template <bool ACC, bool TG>
-__global__ void __launch_bounds__(256, GA_POINT_Q4_WAVES)
-sga_bwd_point_q4(const float *__restrict__ x, float *__restrict__ gradX, PointArgs pa, int D, int H, int W, i64 npix)
-{
-  const i64 HW = (i64)H * W;
-  const i64 nquad = npix >> 2;
-  const i64 stride = (i64)gridDim.x * blockDim.x;
-  const int bid = GA_POINT_XCD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int q = threadIdx.x & 3;                         // the lane's direction: 0 down, 1 up, 2 right, 3 left
-  // Addresses: a UNIFORM plane pointer (scalar registers, advanced by the scalar unit) + the lane's constant 32-bit byte offset
-  // (the launcher checks that every volume, and the four directions' volumes measured from direction 0's, stay below 4 GB):
-  // no vector address arithmetic per plane except one add for the adjoint volume, whose plane stride depends on the lane.
-  const unsigned dG = (unsigned)(reinterpret_cast<const char *>(q == 0 ? pa.G[0] : q == 1 ? pa.G[1] : q == 2 ? pa.G[2] : pa.G[3]) -
-                                 reinterpret_cast<const char *>(pa.G[0]));
-  const unsigned dA = (unsigned)(reinterpret_cast<const char *>(q == 0 ? pa.A[0] : q == 1 ? pa.A[1] : q == 2 ? pa.A[2] : pa.A[3]) -
-                                 reinterpret_cast<const char *>(pa.A[0]));
-  // (selected, not indexed: a lane-dependent index into the argument struct would go through memory)
-  const float *gq = q == 0 ? pa.g[0] : q == 1 ? pa.g[1] : q == 2 ? pa.g[2] : pa.g[3];
-  float *gwq = q == 0 ? pa.gw[0] : q == 1 ? pa.gw[1] : q == 2 ? pa.gw[2] : pa.gw[3];
-  const char *const G0 = reinterpret_cast<const char *>(pa.G[0]);
-  const char *const A0 = reinterpret_cast<const char *>(pa.A[0]);
-  const char *const X0 = reinterpret_cast<const char *>(x);
-  char *const GX0 = reinterpret_cast<char *>(gradX);
-  const i64 pstep = 4 * HW;                              // bytes per plane (API layout)
-  // (the loop is wave-uniform -- lanes past the last quad redo it and store nothing: every lane of a wave takes part in every DPP
-  // operation, which is what the CPU emulator's lockstep model requires and costs nothing on the device)
-  for (i64 l0 = (i64)bid * blockDim.x + (threadIdx.x & ~63u); (l0 >> 2) < nquad; l0 += stride) {
-    const i64 lidx = l0 + (threadIdx.x & 63u);
-    const bool live = (lidx >> 2) < nquad;
-    const i64 pidx = (live ? (lidx >> 2) : nquad - 1) << 2;      // first pixel of the quad (all four lanes of a quad agree)
-    const i64 s = pidx / HW, pix = pidx - s * HW;
-    const int h = (int)(pix / W), w = (int)(pix - (i64)h * W);
-    const i64 vb = s * D * HW + pix;
-    const i64 gbo = s * 5 * HW + pix;
-    // adjoint volume: API layout, or (vertical directions, TG) the tiled private layout of sga_col_kernels.h: the quad's four
-    // columns are contiguous in both
-    const bool tiled = TG && q < 2;
-    const i64 gb = tiled ? (((s * (W >> 4) + (w >> 4)) * (H >> 2) + (h >> 2)) * D) * 64 + (h & 3) * 16 + (w & 15) : vb;
-    const unsigned gstep = tiled ? 256u : (unsigned)pstep;
-    // previous position in the direction's forward scan: a row off (vertical: the aligned quad there) or a column off (horizontal:
-    // the own quad, aligned, plus the one element beside it); hp: which of the four pixels HAVE a previous position
-    const bool up_ok = h > 0, dn_ok = h + 1 < H, lf_ok = w > 0, rt_ok = w + 4 < W;
-    const int a_main = q == 0 ? (up_ok ? -W : 0) : q == 1 ? (dn_ok ? W : 0) : 0;
-    const int a_extra = q == 2 ? (lf_ok ? -1 : 0) : q == 3 ? (rt_ok ? 4 : 3) : 0;
-    const unsigned hp = q == 0 ? (up_ok ? 0xFu : 0u) : q == 1 ? (dn_ok ? 0xFu : 0u) : q == 2 ? (lf_ok ? 0xFu : 0xEu) : (rt_ok ? 0xFu : 0x7u);
-    const unsigned xoff = 4u * (unsigned)(vb + q);                      // x / gradX: the lane's pixel of the quad
-    const unsigned aoff_m = dA + 4u * (unsigned)(vb + a_main), aoff_e = dA + 4u * (unsigned)(vb + a_extra);
-    unsigned goff = dG + 4u * (unsigned)gb;                             // plane dc of the adjoint volume
-    const f4 w0 = *reinterpret_cast<const f4 *>(gq + gbo);
-    const f4 w2 = *reinterpret_cast<const f4 *>(gq + gbo + 2 * HW);
-    const f4 w3 = *reinterpret_cast<const f4 *>(gq + gbo + 3 * HW);
-    float s0[4], s1[4], s2[4], s3[4], sg[4], mx[4], a_m[4], a_0[4];
-    const bool is_r = q == 2, is_l = q == 3;
-    auto shift = [&](const f4 &m, float e, float (&o)[4]) {      // the quad at the previous position from the aligned quad + one element
-      // (the components as opaque scalars: seen as one vector, these selects become an extract at a lane-dependent index, which
-      // the code generator lowers through scratch memory)
-      float m0 = m.x, m1 = m.y, m2 = m.z, m3 = m.w;
-      GA_OPAQUE_VF(m0); GA_OPAQUE_VF(m1); GA_OPAQUE_VF(m2); GA_OPAQUE_VF(m3);
-      o[0] = is_r ? e : is_l ? m1 : m0;
-      o[1] = is_r ? m0 : is_l ? m2 : m1;
-      o[2] = is_r ? m1 : is_l ? m3 : m2;
-      o[3] = is_r ? m2 : is_l ? e : m3;
-    };
-    {
-      const f4 m = *reinterpret_cast<const f4 *>(A0 + aoff_m);
-      const float e = *reinterpret_cast<const float *>(A0 + aoff_e);
-      shift(m, e, a_0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) { s0[i] = s1[i] = s2[i] = s3[i] = sg[i] = 0.f; mx[i] = -INFINITY; a_m[i] = 0.f; }
-    // two planes in flight per step (GA_POINT_DU of sga_bwd_point), written out: left to `#pragma unroll` a body of this size stays
-    // a loop, and the per-plane registers indexed by its counter go to scratch
-    f4 Gv0, Gv1, Am0, Am1;
-    float Ae0, Ae1, xq0, xq1, gxq0 = 0.f, gxq1 = 0.f;
-    auto load_plane = [&](int d, unsigned gofs, f4 &Gv, f4 &Am, float &Ae, float &xq, float &gxq) {
-      // (every load unconditional, plane indices clamped: see sga_bwd_point)
-      const int dcl = d < D ? d : D - 1, dn = d + 1 < D ? d + 1 : D - 1;
-      const char *xs = X0 + (i64)dcl * pstep, *as = A0 + (i64)dn * pstep;      // uniform
-      Gv = stream_load<(GA_NT_LOADS & 2) != 0>(reinterpret_cast<const f4 *>(G0 + gofs));
-      Am = stream_load<(GA_NT_LOADS & 2) != 0>(reinterpret_cast<const f4 *>(as + aoff_m));      // A[pp][d+1]
-      Ae = stream_load<(GA_NT_LOADS & 2) != 0>(reinterpret_cast<const float *>(as + aoff_e));
-      xq = stream_load<(GA_NT_LOADS & 8) != 0>(reinterpret_cast<const float *>(xs + xoff));
-      if (ACC) gxq = *reinterpret_cast<const float *>(GX0 + (i64)dcl * pstep + xoff);
-    };
-    auto compute_plane = [&](int d, const f4 &Gv, const f4 &Am, float Ae, float xq, float gxq) {
-      const float G_[4] = {Gv.x, Gv.y, Gv.z, Gv.w};
-      const float w0_[4] = {w0.x, w0.y, w0.z, w0.w}, w2_[4] = {w2.x, w2.y, w2.z, w2.w}, w3_[4] = {w3.x, w3.y, w3.z, w3.w};
-      const float xv[4] = {dpp_perm_f<DPP_QP_BCAST0>(xq), dpp_perm_f<DPP_QP_BCAST1>(xq), dpp_perm_f<DPP_QP_BCAST2>(xq),
-                           dpp_perm_f<DPP_QP_BCAST3>(xq)};
-      float a_p[4], tot[4];
-      shift(Am, Ae, a_p);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float r = G_[i] * w0_[i];
-        if (d == 0) r = fmaf(G_[i], w2_[i], r);
-        if (d == D - 1) r = fmaf(G_[i], w3_[i], r);
-        // the four directions of the pixel sit in the four lanes of the quad
-        r += dpp_perm_f<DPP_QP_XOR1>(r);
-        r += dpp_perm_f<DPP_QP_XOR2>(r);
-        tot[i] = r;
-        s0[i] = fmaf(G_[i], xv[i], s0[i]);
-        sg[i] += G_[i];
-        s1[i] = fmaf(G_[i], a_0[i], s1[i]);
-        s2[i] = fmaf(G_[i], d >= 1 ? a_m[i] : xv[i], s2[i]);
-        s3[i] = fmaf(G_[i], d + 1 < D ? a_p[i] : xv[i], s3[i]);
-        mx[i] = fmaxf(mx[i], a_0[i]);
-        a_m[i] = a_0[i];
-        a_0[i] = a_p[i];
-      }
-      // every lane of the quad holds the four sums: its first lane stores them, 16 bytes
-      if (ACC) {      // (the lane's old gradX value belongs to pixel q)
-        const float o0 = dpp_perm_f<DPP_QP_BCAST0>(gxq), o1 = dpp_perm_f<DPP_QP_BCAST1>(gxq), o2 = dpp_perm_f<DPP_QP_BCAST2>(gxq),
-                    o3 = dpp_perm_f<DPP_QP_BCAST3>(gxq);
-        tot[0] += o0; tot[1] += o1; tot[2] += o2; tot[3] += o3;
-      }
-      if (live && q == 0)
-        stream_store<(GA_NT_STORES & 8) != 0>(reinterpret_cast<f4 *>(GX0 + (i64)d * pstep + xoff), f4{tot[0], tot[1], tot[2], tot[3]});
-    };
-    for (int dc = 0; dc < D; dc += 2) {
-      load_plane(dc, goff, Gv0, Am0, Ae0, xq0, gxq0);
-      load_plane(dc + 1, dc + 1 < D ? goff + gstep : goff, Gv1, Am1, Ae1, xq1, gxq1);
-      goff += 2u * gstep;
-      compute_plane(dc, Gv0, Am0, Ae0, xq0, gxq0);
-      if (dc + 1 < D) compute_plane(dc + 1, Gv1, Am1, Ae1, xq1, gxq1);
-    }
-    if (!live) continue;
-    float *gw = gwq + gbo;
-    *reinterpret_cast<f4 *>(gw) = f4{s0[0], s0[1], s0[2], s0[3]};
-    *reinterpret_cast<f4 *>(gw + HW) = f4{(hp & 1u) ? s1[0] : 0.f, (hp & 2u) ? s1[1] : 0.f, (hp & 4u) ? s1[2] : 0.f, (hp & 8u) ? s1[3] : 0.f};
-    *reinterpret_cast<f4 *>(gw + 2 * HW) = f4{(hp & 1u) ? s2[0] : 0.f, (hp & 2u) ? s2[1] : 0.f, (hp & 4u) ? s2[2] : 0.f, (hp & 8u) ? s2[3] : 0.f};
-    *reinterpret_cast<f4 *>(gw + 3 * HW) = f4{(hp & 1u) ? s3[0] : 0.f, (hp & 2u) ? s3[1] : 0.f, (hp & 4u) ? s3[2] : 0.f, (hp & 8u) ? s3[3] : 0.f};
-    *reinterpret_cast<f4 *>(gw + 4 * HW) = f4{(hp & 1u) ? sg[0] * mx[0] : 0.f, (hp & 2u) ? sg[1] * mx[1] : 0.f, (hp & 4u) ? sg[2] * mx[2] : 0.f,
-                                              (hp & 8u) ? sg[3] * mx[3] : 0.f};
   }
 }
 

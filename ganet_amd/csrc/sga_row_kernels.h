@@ -182,11 +182,7 @@ sga_row_fwd(const float *__restrict__ x, const float *__restrict__ g, float *__r
           for (int i = 0; i < DPL; i++) xs[i] = f4_get(xv[i], kk);
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
-#if GA_SCAN_ABLATE & 1
-          for (int i = 0; i < DPL; i++) Ap[i] = xs[i] + w[0];     // (A/B only: the tile path without the recurrence)
-#else
           fwd_step<GD, DPL, FULL>(xs, w, Ap, m, k == 0 && first_group, c, D);
-#endif
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Ap[i]);
         }
@@ -371,11 +367,7 @@ sga_row_bwdg(const float *__restrict__ g, const uint8_t *__restrict__ mask,
 #pragma unroll
           for (int t = 0; t < 5; t++) w[t] = f4_get(wv[t], kk);
           const int kpv = (int)(((kk < 2 ? k01 : k23) >> (16 * (kk & 1))) & 0xffffu);
-#if GA_SCAN_ABLATE & 1
-          for (int i = 0; i < DPL; i++) Gn[i] = go[i] + w[0] + (float)kpv;
-#else
           bwdg_step<GD, DPL, uint8_t, FULL, true>(go, mk, Gn, wn, sgn, w, kpv, !(k == 0 && first_group), c, D, dir);
-#endif
 #pragma unroll
           for (int i = 0; i < DPL; i++) f4_set(ov[i], kk, Gn[i]);
         }

@@ -216,20 +216,13 @@ class _LgaChain(Function):
                 gradFilters = torch.empty_like(filters)
                 gt1p, gx = torch.empty_like(t1p), torch.empty_like(x)      # the intermediate's gradient is private too
                 lib, st, r = _lib(), _stream(), ctx.radius
-                # GANET_LGA_FG_FUSED=1: both filter-gradient passes in one launch, after the first data-backward (it needs gt1p);
-                # built in round 4 after the last GPU minute: off until it has been measured
-                fused = os.environ.get("GANET_LGA_FG_FUSED", "0") == "1" and W % 4 == 0 and x.data_ptr() % 16 == 0
-                if not fused:
-                    lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, r, 0, 1, 0, st)
+                lib.call("ganet_lga_filter_grad_paired", _p(t1p), _p(g), _p(gradFilters), B, D, H, W, r, 0, 1, 0, st)
                 edge = getattr(ctx, "edge", None)
                 if edge is not None:
                     lib.call("ganet_lga_apply_paired_edges", _p(g), _p(filters), _p(gt1p), _p(edge), B, D, H, W, r, 1, 0, 1, st)
                 else:
                     lib.call("ganet_lga_apply_paired", _p(g), _p(filters), _p(gt1p), B, D, H, W, r, 1, 0, 1, st)
-                if fused:
-                    lib.call("ganet_lga2_filter_grad", _p(t1p), _p(g), _p(x), _p(gt1p), _p(gradFilters), B, D, H, W, r, 0, st)
-                else:
-                    lib.call("ganet_lga_filter_grad_paired", _p(x), _p(gt1p), _p(gradFilters), B, D, H, W, r, 1, 0, 1, st)
+                lib.call("ganet_lga_filter_grad_paired", _p(x), _p(gt1p), _p(gradFilters), B, D, H, W, r, 1, 0, 1, st)
                 if edge is not None:
                     lib.call("ganet_lga_apply_paired_edges", _p(gt1p), _p(filters), _p(gx), _p(edge), B, D, H, W, r, 1, 1, 0, st)
                 else:

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 9
+#define GANET_ABI_VERSION 10      /* v10 = v8's entries (v9's ganet_lga2_filter_grad lost its A/B and is gone) */
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -190,15 +190,6 @@ int ganet_lga_apply_paired_edges(const float *x, const float *f, float *y, float
 int ganet_lga_filter_grad_paired(const float *x, const float *gy, float *gf, int B, int D, int H, int W, int radius,
                                  int accumulate_gf, int x_paired, int gy_paired, void *stream);
 
-/* ABI v9.  BOTH filter-gradient passes of a two-pass chain's backward (Lga2Function.backward, functions/GANet.py:190-203: two
- * lga_cuda_backward calls whose lga_filter_backward halves, GANet_kernel.cu:1177-1216, add into the same gradFilters) in one
- * launch:  gf (=|+=)  gF(t1p, gy) + gF(x, gt1p)  with t1p = the chain's intermediate and gt1p = its gradient, both
- * pair-interleaved (ganet_lga_apply_paired), gy and x in the API layout.  The second pass goes on adding into the
- * accumulators of the first: gf is written once instead of written, read and written again, and one launch goes.
- * radius 2, W % 4 == 0, 16-byte aligned volumes; GANET_E_UNSUPPORTED otherwise (then: two ganet_lga_filter_grad_paired calls). */
-int ganet_lga2_filter_grad(const float *t1p, const float *gy, const float *x, const float *gt1p, float *gf, int B, int D, int H, int W,
-                           int radius, int accumulate_gf, void *stream);
-
 /* One LGA pass backward: gx fully overwritten; gf written (accumulate_gf = 0) or
  * accumulated into (accumulate_gf = 1, what chained LGA2/LGA3 rely on,
  * functions/GANet.py:197-199).  gx may alias x (the reference's chained
@@ -293,9 +284,6 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_WIDE_COL=0|1|2  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
  *                         D <= 192): never | for inputs with few column blocks and D >= 96 (default; measured on
  *                         [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40) | whenever the kernel applies (tests)
- *   GANET_SGA_POINT_Q4 = 0|1  the per-pixel gradient kernel of ganet_sga_backward / ganet_sga_backward_point with one pixel and four
- *                         directions per lane (default) | four pixels of ONE direction per lane, 16-byte loads (W % 4 == 0,
- *                         16-byte aligned volumes below 4 GB; verified under the emulator, not measured yet)
  *   GANET_LGA_WAVE = 0|1  LGA kernels: 256-thread tiles (any radius; the fallback) | wave-autonomous, LDS-DMA, FMAs packed
  *                         along plane pairs (radius <= 2; default)
  *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
@@ -303,11 +291,10 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so
  *                         a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average at 240x624).  Default 1
  *                         (measured: forward pass 0.103 -> 0.0955 ms); n > 1: n SIMDs assumed (tests)
- *   GANET_LGA_WG = 0|1|2  the same kernels and the filter gradient (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE LDS ring per 256-thread workgroup on 32 x 8 pixel
- *                         tiles (the halo'd tile staged once for four waves: 12 rows fetched for 8 instead of 24), the four
- *                         waves meeting at a barrier per plane pair (1) or kept within one pair of each other by progress
- *                         flags in LDS (2) | one ring per wave on 32 x 2 tiles (0, default: the workgroup forms are verified
- *                         under the emulator and on the parity tests, their step time is not measured yet)
+ *   GANET_LGA_WG = 0|1    the same kernels and the filter gradient (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE
+ *                         LDS ring per 256-thread workgroup on 32 x 8 pixel tiles (the halo'd tile staged once for four waves:
+ *                         12 rows fetched for 8 instead of 24), the four waves meeting at a barrier per plane pair (1, default:
+ *                         whole step -4.4 % on the device, profiles/r8b_*) | one ring per wave on 32 x 2 tiles (0, the fallback)
  * Read by ganet_amd.functions.GANet, not by this library: GANET_LGA_PAIRED=0 keeps the intermediate volume of a two-pass
  * chain in the API layout instead of pair-interleaved (ganet_lga_apply_paired; default on, measured -7 % on Lga2Function
  * fwd+bwd); GANET_SGA_SAVE=recompute selects the reference's memory profile.  GANET_TRACE_DISPATCH=1 prints which LGA kernel

@@ -13,7 +13,7 @@ from ganet_amd import _native
 dev = torch.device("cuda:0")
 graphs = {}
 DEFAULTS = {}
-RESET = ("GANET_SGA_TILED", "GANET_SGA_POINT_Q4", "GANET_LGA_WG", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
+RESET = ("GANET_SGA_TILED", "GANET_LGA_WG", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
 
 
 def reset_options(lib, libname, defaults):
@@ -36,12 +36,11 @@ for idx, name in enumerate(sys.argv[1:]):
     libname, _, optstr = name.partition("@")          # lib.so@OPTION=value,OPTION=value: ganet_set_option before the capture
     _native._LIB = _native.CApi(os.path.join(ROOT, "ganet_amd", libname), strict=False)
     os.environ.pop("GANET_LGA_EDGES", None)
-    os.environ.pop("GANET_LGA_FG_FUSED", None)
     # options are process-wide in a loaded library: every entry starts from that library's own defaults
     reset_options(_native._LIB, libname, DEFAULTS)
     for kv in filter(None, optstr.split(",")):
         k, v = kv.split("=")
-        if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE", "GANET_LGA_EDGES", "GANET_LGA_FG_FUSED"):      # read by the Python layer from the environment at every call
+        if k in ("GANET_LGA_PAIRED", "GANET_SGA_SAVE", "GANET_LGA_EDGES"):      # read by the Python layer from the environment at every call
             os.environ[k] = v
         else:
             _native._LIB.set_option(k, int(v))

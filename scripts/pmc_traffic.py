@@ -4,7 +4,8 @@
    FETCH_SIZE tallies 128-byte requests at 64 B on gfx950.)  Infinity-Cache hits are included: this is traffic at the
    L2 <-> fabric boundary, an upper bound of DRAM traffic.
    python scripts/pmc_traffic.py gpurun_out/<tag>/summary.txt profiles/traffic_pmc.json"""
-import json, sys
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 txt = open(sys.argv[1]).read()
 out = {}
 for blk in txt.split("== ")[1:]:
@@ -21,6 +22,7 @@ for blk in txt.split("== ")[1:]:
     w64 = d.get("TCC_EA0_WRREQ_64B_sum", 0)
     wr = w64 * 64 + max(0.0, d.get("TCC_EA0_WRREQ_sum", 0) - w64) * 32
     out[name] = {"read_bytes": int(rd), "write_bytes": int(wr), "duration_us_profiled": d.get("duration_us")}
-json.dump({"source": sys.argv[1], "method": "TCC_EA0_RDREQ/WRREQ request counts x request size, mean per dispatch (rocprofv3 --pmc, own passes)",
+import bench      # csrc_tree_hash(): the kernel sources these counters were measured on (bench.py warns when they differ from HEAD's)
+json.dump({"source": sys.argv[1], "csrc_tree": bench.csrc_tree_hash(), "method": "TCC_EA0_RDREQ/WRREQ request counts x request size, mean per dispatch (rocprofv3 --pmc, own passes)",
            "kernels": out}, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -102,7 +102,6 @@ struct State {
   bool late_lds = false;
   long lds_late_landed = 0;
   int lgkm_slack = 0, vm_slack = 0;
-  int flag_slack = 0;            // tests only: progress-flag polls accept a wave that many steps further behind
   // order in which the runnable threads of a block are resumed between two barriers: 0 = ascending thread index,
   // 1 = descending.  A hand-off through LDS that lacks a barrier is decided by whichever thread runs first; results that
   // are the same in both orders do not depend on that luck.

@@ -19,13 +19,9 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("GANET_TEST_WG") != "1",
-                    reason="GANET_LGA_FG_FUSED / GANET_LGA_WG (default off) were written after round 4's last GPU minute: first device "
-                           "run in scripts/gpu_r5_wg.sh (GANET_TEST_WG=1 enables this test)")
-@pytest.mark.parametrize("fused,wg", [("1", 0), ("1", 1)] + ([("0", 2)] if "2" in __import__("os").environ.get("GANET_TEST_WG_FORMS", "1,2") else []))
-def test_lga2_module_with_round5_candidates(torch_mod, port_oracle, monkeypatch, fused, wg):
-    """LGA2 through autograd with the fused two-pass filter gradient (ganet_lga2_filter_grad) and / or the workgroup rings"""
-    monkeypatch.setenv("GANET_LGA_FG_FUSED", fused)
+@pytest.mark.parametrize("wg", [1, 0])
+def test_lga2_module_on_workgroup_and_one_wave_rings(torch_mod, port_oracle, wg):
+    """LGA2 through autograd with the workgroup rings (default) and with the one-wave rings they fall back to"""
     torch = torch_mod
     import torch.nn.functional as F
     import ganet_amd.modules.GANet as M
@@ -40,7 +36,7 @@ def test_lga2_module_with_round5_candidates(torch_mod, port_oracle, monkeypatch,
         y.backward(gy)
         torch.cuda.synchronize()
     finally:
-        _native.lib().set_option("GANET_LGA_WG", 0)
+        _native.lib().set_option("GANET_LGA_WG", 1)
     o_y, ins = port_oracle.lga_chain_forward(_np(x), _np(f), 2, 2)
     o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy), 2)
     assert np.abs(_np(y) - o_y).max() <= pc.TOL

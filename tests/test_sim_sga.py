@@ -234,43 +234,3 @@ def test_tiled_workspace_random_shapes(sim, port_oracle):
             assert max(err.values()) < 3e-5, (shape, err)
     finally:
         sim.set_option("GANET_SGA_TILED", was)
-
-
-# GANET_SGA_POINT_Q4 (sga_bwd_point_q4): the per-pixel gradient kernel with four pixels of ONE direction per lane -- 16-byte loads,
-# the quad's x shared by DPP broadcasts, the four directions' gradX terms summed across the quad's lanes.  Shapes: one quad per
-# row (no left AND no right neighbour quad), rows of 2 .. 20 quads, one row / one plane / odd and even depths (two planes in
-# flight per step), several slices, pixel counts that do not fill the last wave, the tiled adjoint workspace and the API layout.
-@pytest.mark.parametrize("tiled", [0, 1])
-@pytest.mark.parametrize("shape", [(1, 1, 1, 1, 4), (1, 1, 2, 3, 4), (1, 2, 5, 2, 8), (1, 1, 9, 4, 16), (2, 1, 6, 8, 32), (1, 3, 7, 5, 12),
-                                   (1, 1, 33, 4, 48), (1, 1, 4, 12, 80), (2, 2, 3, 4, 20), (1, 1, 65, 8, 16)])
-def test_point_kernel_with_pixel_quads(sim, port_oracle, shape, tiled):
-    was = sim.get_option("GANET_SGA_TILED")
-    sim.set_option("GANET_SGA_TILED", tiled)
-    sim.set_option("GANET_SGA_POINT_Q4", 1)
-    try:
-        x, gs, go = pc.sga_inputs(shape, seed=sum(shape) + 5 * tiled)
-        err = pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go))
-        assert max(err.values()) < 3e-5, (shape, err)
-    finally:
-        sim.set_option("GANET_SGA_POINT_Q4", 0)
-        sim.set_option("GANET_SGA_TILED", was)
-
-
-def test_point_kernel_with_pixel_quads_is_what_runs_and_falls_back(sim, port_oracle):
-    """W % 4 != 0: the option changes nothing (one pixel per lane); W % 4 == 0: a different summation order over the directions,
-    i.e. results that agree to rounding but not bit for bit with the one-pixel-per-lane kernel on a shape where that shows"""
-    res = {}
-    for q4 in (0, 1):
-        sim.set_option("GANET_SGA_POINT_Q4", q4)
-        try:
-            for shape in [(1, 1, 9, 3, 7), (1, 2, 17, 4, 16)]:
-                x, gs, go = pc.sga_inputs(shape, seed=11)
-                got = {}
-                pc.check_sga_forward_backward(sim, DEV, x, gs, go, _oracle_want(port_oracle, x, gs, go), results=got)
-                res[q4, shape] = got
-        finally:
-            sim.set_option("GANET_SGA_POINT_Q4", 0)
-    assert all(np.array_equal(res[0, (1, 1, 9, 3, 7)][k], res[1, (1, 1, 9, 3, 7)][k]) for k in res[0, (1, 1, 9, 3, 7)])
-    a, b = res[0, (1, 2, 17, 4, 16)], res[1, (1, 2, 17, 4, 16)]
-    assert all(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-5 for k in a)
-    assert any(not np.array_equal(a[k], b[k]) for k in a), "the quad kernel did not run"
