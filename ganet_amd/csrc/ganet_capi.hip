@@ -65,7 +65,7 @@ struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
   std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
-  std::atomic<int> lga_wg{1};       // plane-pair LGA kernels (forward / data-backward and filter gradient, API-layout and pair-interleaved operands): 1 ONE x ring per 256-thread workgroup on 32 x 8 tiles, a workgroup barrier per plane pair (lga_apply_pp_w*, lga_filter_grad_pp_w*; measured: whole step -4.4 %, profiles/r8b_*), 0 one ring per wave on 32 x 2 tiles (the fallback; also taken where W % 4 != 0)
+  std::atomic<int> lga_wg{1};       // plane-pair LGA forward / data-backward kernels (API-layout and pair-interleaved operands): 1 ONE x ring per 256-thread workgroup on 32 x 8 tiles, a workgroup barrier per plane pair (lga_apply_pp_w*; measured: whole step -1.4 ... -3.5 % over five boxes, profiles/r8*_ab_step*), 0 one ring per wave on 32 x 2 tiles (the fallback; also taken where W % 4 != 0).  The filter gradient stays on one-wave rings (its workgroup form was measured: no gain, removed)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -659,17 +659,7 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired && opts().lga_wg) {                               // x through one ring per 256-thread workgroup (32 x 8 tiles)
-    sg.tiles_y = (H + 7) / 8;
-    const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    GA_LAUNCH((lga_filter_grad_pp_wxp<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-  }
-  else if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
-  else if (GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // x through one ring per 256-thread workgroup (32 x 8 tiles)
-    sg.tiles_y = (H + 7) / 8;
-    const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-    GA_LAUNCH((lga_filter_grad_pp_wgypx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-  }
+  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");
@@ -718,12 +708,6 @@ int launch_lga_gf(const float *x, const float *gy, float *gf, int B, int D, int 
         bool planar = false;
         if constexpr (R == 2) {
           planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);
-          if (planar && opts().lga_wg) {                  // x through one ring per 256-thread workgroup (32 x 8 tiles)
-            sg.tiles_y = (H + 7) / 8;
-            const i64 wg_items = (i64)sg.tiles_x * sg.tiles_y * B;
-            GA_LAUNCH((lga_filter_grad_pp_wx<2, 3, 0>), dim3((unsigned)wg_items), dim3(256), st, x, gy, gf, geo, sg, acc);
-            return check_launch("lga filter grad (plane pairs, workgroup ring)");
-          }
           if (planar) GA_LAUNCH((lga_filter_grad_pp_x<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
         }
         if (!planar) GA_LAUNCH((lga_filter_grad_pp<R, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);

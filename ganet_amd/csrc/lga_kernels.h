@@ -390,9 +390,6 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_NR
 #define LGAP_NR 5                // plane-PAIR slots per wave (1792 B each at R = 2)
 #endif
-#ifndef LGAP_WG_NR_FG
-#define LGAP_WG_NR_FG LGAP_WG_NR      // the filter gradient's x ring (its steady groups are NR steps long: at D = 193, 8 slots leave 17 of 97 steps to the general body, 6 leave 13)
-#endif
 #ifndef LGAP_WG_NR
 #define LGAP_WG_NR 8      // ring slots (4 KB each) of the workgroup-shared ring: 34 KB per workgroup, three workgroups per CU (see the march of lga_apply_pp.inc)
 #endif
@@ -986,28 +983,6 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_GYP 1
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
-#include "lga_filter_grad_pp.inc"
-
-// x through ONE ring per 256-thread workgroup (32 x 8 tiles, a barrier per pair-step; GANET_LGA_WG): pair-interleaved x,
-#define GA_FG_NAME lga_filter_grad_pp_wxp
-#define GA_FG_XP 4
-#define GA_FG_GYP 0
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-// API-layout x staged planar,
-#define GA_FG_NAME lga_filter_grad_pp_wx
-#define GA_FG_XP 3
-#define GA_FG_GYP 0
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
-#include "lga_filter_grad_pp.inc"
-// and the same with gy pair-interleaved
-#define GA_FG_NAME lga_filter_grad_pp_wgypx
-#define GA_FG_XP 3
-#define GA_FG_GYP 1
-#define GA_FG_SLOT 1024
-#define GA_FG_NDC 1
 #include "lga_filter_grad_pp.inc"
 
 // ---- filter backward --------------------------------------------------------------

@@ -291,10 +291,11 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so
  *                         a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average at 240x624).  Default 1
  *                         (measured: forward pass 0.103 -> 0.0955 ms); n > 1: n SIMDs assumed (tests)
- *   GANET_LGA_WG = 0|1    the same kernels and the filter gradient (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE
- *                         LDS ring per 256-thread workgroup on 32 x 8 pixel tiles (the halo'd tile staged once for four waves:
- *                         12 rows fetched for 8 instead of 24), the four waves meeting at a barrier per plane pair (1, default:
- *                         whole step -4.4 % on the device, profiles/r8b_*) | one ring per wave on 32 x 2 tiles (0, the fallback)
+ *   GANET_LGA_WG = 0|1    the same kernels (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE LDS ring per 256-thread
+ *                         workgroup on 32 x 8 pixel tiles (the halo'd tile staged once for four waves: 12 rows fetched for 8 instead
+ *                         of 24), the four waves meeting at a barrier per plane pair (1, default: whole step -1.4 ... -3.5 % over
+ *                         five boxes, profiles/r8*_ab_step*) | one ring per wave on 32 x 2 tiles (0, the fallback).  The filter
+ *                         gradient always runs one ring per wave (its workgroup form was measured in round 5: no gain, removed)
  * Read by ganet_amd.functions.GANet, not by this library: GANET_LGA_PAIRED=0 keeps the intermediate volume of a two-pass
  * chain in the API layout instead of pair-interleaved (ganet_lga_apply_paired; default on, measured -7 % on Lga2Function
  * fwd+bwd); GANET_SGA_SAVE=recompute selects the reference's memory profile.  GANET_TRACE_DISPATCH=1 prints which LGA kernel

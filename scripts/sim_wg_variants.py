@@ -1,7 +1,7 @@
 """The workgroup-ring LGA chains on emulator builds with other compile-time ring parameters -- a variant library must be right
-before GPU minutes are spent on timing it:  python scripts/sim_wg_variants.py -DLGAP_WG_NR=10,-DLGAP_WG_NR_FG=6
+before GPU minutes are spent on timing it:  python scripts/sim_wg_variants.py -DLGAP_WG_NR=10
 (round-robin and one-wave-ahead schedules, both thread orders, copies and LDS reads landing late, guard pages).
-Round 4: NR = 5 / 6 / 10, NR_FG = 6 / 8 -- no failures."""
+Rounds 4 - 5: NR = 5 / 6 / 7 / 10 -- no failures."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
