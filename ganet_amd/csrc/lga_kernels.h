@@ -441,6 +441,8 @@ template <int R> struct LgaPCfg {
 // a kernel without such constructs need not preserve it around the hand-written copies.  scripts/isa_loop_check.py asserts
 // that no instruction outside the copy batches touches m0 in these kernels.  GA_M0_SAVE = 1 restores the save / restore pair
 // (two scalar instructions per batch; the march is bound by its instruction count, profiles/r5c_* ... r5f_*).
+// ("m0" in the clobber lists instead, ADVICE r4: hipcc answers "inline asm clobber list contains reserved registers: M0 ... clobbering
+// them may lead to undefined behaviour" -- for a reserved register the list is not the contract; the ISA check above is.)
 #ifndef GA_M0_SAVE
 #define GA_M0_SAVE 0
 #endif

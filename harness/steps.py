@@ -73,9 +73,10 @@ def train_step(model, optimizer, name, left, right, target, max_disp, crit):
     optimizer.zero_grad()
     outputs = model(left, right)
     if int(nvalid) == 0:
-        # zero loss that still reaches every parameter; nan_to_num first: 0 * (a non-finite output) would be NaN and poison
-        # the all-reduced gradients of the ranks that do have valid pixels
-        loss = sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).sum() for o in outputs) * 0.0
+        # A zero loss that reaches every parameter WITHOUT going through the data path: the forward above ran (its collectives --
+        # SyncBN statistics -- stay aligned with the other ranks), but a non-finite activation anywhere in it would turn
+        # 0 * output into NaN weight gradients and poison the all-reduce of the ranks that do have valid pixels.
+        loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * 0.0
         err = loss.detach()
     else:
         loss = loss_mix(name, outputs, target, mask, crit)
