@@ -39,7 +39,7 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
         raise RuntimeError("hipcc not found and no prebuilt libganet_hip.so")
     objs, procs = [], []
     for src, extra in SOURCES.items():
-        obj = os.path.join(_HERE, "csrc", src + ".o")
+        obj = os.path.join(_HERE, "csrc", f"{src}.{os.getpid()}.o")      # (two processes building at once must not share object files)
         cmd = [hipcc] + HIPCC_FLAGS + extra + list(extra_flags) + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -48,13 +48,13 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + LIB_SONAME] + objs + ["-o", out + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + LIB_SONAME] + objs + ["-o", f"{out}.{os.getpid()}.tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     for o in objs:
         os.remove(o)
-    os.replace(out + ".tmp", out)
+    os.replace(f"{out}.{os.getpid()}.tmp", out)
     return out
 
 

@@ -64,8 +64,7 @@ int check_launch(const char *what)
 struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
-  std::atomic<int> lga_wave{1};     // LGA: 1 wave-autonomous plane-pair kernels (lga_apply_pp / lga_filter_grad_pp, radius <= 2), 0 the 256-thread tile kernels (any radius; the fallback)
-  std::atomic<int> lga_wg{1};       // plane-pair LGA forward / data-backward kernels (API-layout and pair-interleaved operands): 1 ONE x ring per 256-thread workgroup on 32 x 8 tiles, a workgroup barrier per plane pair (lga_apply_pp_w*; measured: whole step -1.4 ... -3.5 % over five boxes, profiles/r8*_ab_step*), 0 one ring per wave on 32 x 2 tiles (the fallback; also taken where W % 4 != 0).  The filter gradient stays on one-wave rings (its workgroup form was measured: no gain, removed)
+  std::atomic<int> lga_wave{2};     // LGA kernel family (radius <= 2): 2 plane-pair kernels, the forward / data-backward with ONE x ring per 256-thread workgroup on 32 x 8 tiles and a barrier per plane pair (lga_apply_pp_w*; default: whole step -1.4 ... -3.5 % over five boxes against 1, profiles/r8*_ab_step*; where W % 4 != 0 on API-layout x: as 1), 1 plane-pair kernels with one ring per wave on 32 x 2 tiles (lga_apply_pp_* / lga_filter_grad_pp_*: what the filter gradient always runs; its workgroup form was measured: no gain, removed), 0 the 256-thread tile kernels (any radius; the general fallback)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -86,7 +85,6 @@ void load_env_options()
   geti("GANET_SGA_TILED", g_opt.sga_tiled);
   geti("GANET_LGA_SEGS", g_opt.lga_segs);
   geti("GANET_LGA_MIX", g_opt.lga_mix);
-  geti("GANET_LGA_WG", g_opt.lga_wg);
   geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
   geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
   geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
@@ -571,12 +569,13 @@ int launch_lga_fwd(const float *x, const float *f, float *y, int B, int D, int H
   LgaGeom geo;
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   if constexpr (R <= 2) {
-    if (opts().lga_wave && (i64)H * W < (1ll << 28)) {
+    const int family = opts().lga_wave;
+    if (family && (i64)H * W < (1ll << 28)) {
       i64 items;
       bool planar = false;
       if constexpr (R == 2) planar = GA_LGA_PLANAR && W % 4 == 0 && aligned16(x);      // input staged by 16-byte copies
       if constexpr (R == 2) {
-        if (planar && opts().lga_wg) {                      // one ring per 256-thread workgroup (32 x 8 tiles)
+        if (planar && family == 2) {                      // one ring per 256-thread workgroup (32 x 8 tiles)
           const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
           if (items < (1ll << 31)) {
             if (transposed) GA_LAUNCH((lga_apply_pp_wx<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx);
@@ -616,7 +615,8 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
   geo.D = D; geo.H = H; geo.W = W; geo.HW = (i64)H * W;
   i64 items;
   float *const none = nullptr;
-  if (x_paired && opts().lga_wg) {                                       // one ring per 256-thread workgroup (32 x 8 tiles)
+  const bool wg_ring = opts().lga_wave == 2;
+  if (x_paired && wg_ring) {                                       // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
       if (transposed) GA_LAUNCH((lga_apply_pp_wpi<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
@@ -624,7 +624,7 @@ int launch_lga_paired(const float *x, const float *f, float *y, int B, int D, in
       return check_launch("lga apply (plane pairs, interleaved input, workgroup ring)");
     }
   }
-  if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && opts().lga_wg) {      // one ring per 256-thread workgroup (32 x 8 tiles)
+  if (!x_paired && GA_LGA_PLANAR && W % 4 == 0 && wg_ring) {      // one ring per 256-thread workgroup (32 x 8 tiles)
     const LgaSegMix wx = lga_items(W, H, B, D, false, &items, true);
     if (items < (1ll << 31)) {
       if (transposed) GA_LAUNCH((lga_apply_pp_wxo<2, true>), dim3((unsigned)items), dim3(256), st, x, f, y, geo, wx, none, none, edge);
@@ -777,7 +777,6 @@ GA_EXPORT int ganet_get_option(const char *name)
   if (!strcmp(name, "GANET_LGA_WAVE")) return g_opt.lga_wave;
   if (!strcmp(name, "GANET_SGA_TILED")) return g_opt.sga_tiled;
   if (!strcmp(name, "GANET_LGA_MIX")) return g_opt.lga_mix;
-  if (!strcmp(name, "GANET_LGA_WG")) return g_opt.lga_wg;
   if (!strcmp(name, "GANET_LGA_SEGS")) return g_opt.lga_segs;
   if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) return g_opt.wide_scan;
   if (!strcmp(name, "GANET_SGA_WIDE_COL")) return g_opt.wide_col;
@@ -790,11 +789,10 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 {
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
-  if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value ? 1 : 0;
+  if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
   else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
   else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_LGA_WG")) g_opt.lga_wg = value ? 1 : 0;
   else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
@@ -808,11 +806,13 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
   else if (!strcmp(name, "HIPSIM_VMCNT_SLACK")) hipsim::S().vm_slack = value;      // tests: every counted copy wait loosened by `value`
 #endif
   else {
-    // names retired in ABI 7 (their kernels were removed or became the only path): accepted and ignored, so that a caller
-    // written against ABI 6 keeps running; one note per process
+    // names retired in ABI 7 / 10 (their kernels were removed, became the only path, or the switch moved into another option:
+    // GANET_LGA_WG -> GANET_LGA_WAVE = 2 | 1): accepted and ignored, so that a caller written against an older ABI keeps running;
+    // one note per process
     static const char *const retired[] = {"GANET_LGA_BWD_STREAMS", "GANET_LGA_FG_WPS", "GANET_LGA_SPLIT", "GANET_LGA_VMCNT_SAFE",
                                           "GANET_SGA_BLOCK_H", "GANET_SGA_BLOCK_V", "GANET_SGA_GD", "GANET_SGA_GD_H", "GANET_SGA_GD_V",
-                                          "GANET_SGA_INFER_FUSED", "GANET_SGA_MERGE4", "GANET_SGA_POINT_BLOCK", "GANET_SGA_STREAMS"};
+                                          "GANET_SGA_INFER_FUSED", "GANET_SGA_MERGE4", "GANET_SGA_POINT_BLOCK", "GANET_SGA_STREAMS",
+                                          "GANET_LGA_WG", "GANET_SGA_POINT_Q4"};
     for (const char *r : retired)
       if (!strcmp(name, r)) {
         static std::atomic<int> noted{0};

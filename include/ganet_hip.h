@@ -284,18 +284,17 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_WIDE_COL=0|1|2  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
  *                         D <= 192): never | for inputs with few column blocks and D >= 96 (default; measured on
  *                         [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40) | whenever the kernel applies (tests)
- *   GANET_LGA_WAVE = 0|1  LGA kernels: 256-thread tiles (any radius; the fallback) | wave-autonomous, LDS-DMA, FMAs packed
- *                         along plane pairs (radius <= 2; default)
+ *   GANET_LGA_WAVE=0|1|2  LGA kernel family (radius <= 2): 256-thread tiles (any radius; the general fallback) | wave-autonomous
+ *                         plane-pair kernels, LDS-DMA staging, FMAs packed along plane pairs, one ring per wave on 32 x 2 pixel
+ *                         tiles | the same with the forward / data-backward kernels on ONE ring per 256-thread workgroup (32 x 8
+ *                         tiles: the halo'd tile staged once for four waves, 12 rows fetched for 8 instead of 24; a barrier per
+ *                         plane pair).  Default 2 (whole step -1.4 ... -3.5 % over five boxes against 1, profiles/r8*_ab_step*).
+ *                         The filter gradient runs one ring per wave in both (its workgroup form: measured, no gain, removed)
  *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
  *   GANET_LGA_MIX=0|1|n   the same kernels with a MIXED item list: whole tiles first (a whole number per SIMD), the remaining
  *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so
  *                         a pass lasts as long as the SIMD with the most tiles (3 of 2.34 on average at 240x624).  Default 1
  *                         (measured: forward pass 0.103 -> 0.0955 ms); n > 1: n SIMDs assumed (tests)
- *   GANET_LGA_WG = 0|1    the same kernels (W % 4 == 0 for API-layout x, any pair-interleaved x) with ONE LDS ring per 256-thread
- *                         workgroup on 32 x 8 pixel tiles (the halo'd tile staged once for four waves: 12 rows fetched for 8 instead
- *                         of 24), the four waves meeting at a barrier per plane pair (1, default: whole step -1.4 ... -3.5 % over
- *                         five boxes, profiles/r8*_ab_step*) | one ring per wave on 32 x 2 tiles (0, the fallback).  The filter
- *                         gradient always runs one ring per wave (its workgroup form was measured in round 5: no gain, removed)
  * Read by ganet_amd.functions.GANet, not by this library: GANET_LGA_PAIRED=0 keeps the intermediate volume of a two-pass
  * chain in the API layout instead of pair-interleaved (ganet_lga_apply_paired; default on, measured -7 % on Lga2Function
  * fwd+bwd); GANET_SGA_SAVE=recompute selects the reference's memory profile.  GANET_TRACE_DISPATCH=1 prints which LGA kernel

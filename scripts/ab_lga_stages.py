@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch, bench
 from ganet_amd import _native
 DEFAULTS = {}
-RESET = ("GANET_SGA_TILED", "GANET_LGA_WG", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
+RESET = ("GANET_SGA_TILED", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
 
 
 def reset_options(lib, libname, defaults):

@@ -13,7 +13,7 @@ from ganet_amd import _native
 dev = torch.device("cuda:0")
 graphs = {}
 DEFAULTS = {}
-RESET = ("GANET_SGA_TILED", "GANET_LGA_WG", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
+RESET = ("GANET_SGA_TILED", "GANET_LGA_MIX", "GANET_LGA_SEGS", "GANET_LGA_WAVE")
 
 
 def reset_options(lib, libname, defaults):

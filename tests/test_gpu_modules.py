@@ -26,7 +26,7 @@ def test_lga2_module_on_workgroup_and_one_wave_rings(torch_mod, port_oracle, wg)
     import torch.nn.functional as F
     import ganet_amd.modules.GANet as M
     from ganet_amd import _native
-    _native.lib().set_option("GANET_LGA_WG", wg)
+    _native.lib().set_option("GANET_LGA_WAVE", 1 + wg)
     try:
         torch.manual_seed(11)
         x = torch.randn((2, 41, 21, 40), device="cuda", requires_grad=True)
@@ -36,7 +36,7 @@ def test_lga2_module_on_workgroup_and_one_wave_rings(torch_mod, port_oracle, wg)
         y.backward(gy)
         torch.cuda.synchronize()
     finally:
-        _native.lib().set_option("GANET_LGA_WG", 1)
+        _native.lib().set_option("GANET_LGA_WAVE", 2)
     o_y, ins = port_oracle.lga_chain_forward(_np(x), _np(f), 2, 2)
     o_gx, o_gf = port_oracle.lga_chain_backward(ins, _np(f), _np(gy), 2)
     assert np.abs(_np(y) - o_y).max() <= pc.TOL

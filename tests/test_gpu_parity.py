@@ -298,7 +298,7 @@ def test_cost_volume_and_regression(api, dev, port_oracle):
 @pytest.mark.parametrize("shape", [(1, 193, 384, 1248), (2, 193, 528, 960), (1, 193, 241, 624)])
 def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
     """The LGA shapes of BASELINE configs 3 and 5 (KITTI 1248x384; SceneFlow 960x528, 2 samples per GPU) and an odd
-    height: the plane-pair kernels (default, GANET_LGA_WAVE=1) and the 256-thread tile kernels (0, the fallback) are different
+    height: the plane-pair kernels (default, GANET_LGA_WAVE=2; 1 = all of them on one-wave rings) and the 256-thread tile kernels (0, the general fallback) are different
     kernel families and must agree to fp32 rounding, forward, data gradient and filter gradient; the bilinear identity
     <y, gy> == <x, gX> == <f, gF> holds for both -- no oracle in the loop."""
     torch = dev.torch
@@ -309,7 +309,7 @@ def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
     gy = torch.randn(shape, device="cuda", generator=g)
     res = {}
     try:
-        for mode in (1, 0):
+        for mode in (2, 0):
             api.set_option("GANET_LGA_WAVE", mode)
             y, gx, gf = torch.empty_like(xl), torch.empty_like(xl), torch.empty_like(f)
             api.call("ganet_lga_forward", xl.data_ptr(), f.data_ptr(), y.data_ptr(), B, D, H, W, 2, dev.stream)
@@ -318,10 +318,10 @@ def test_lga_model_shapes_wave_kernels_vs_block_kernels(api, dev, shape):
             torch.cuda.synchronize()
             res[mode] = (y, gx, gf)
     finally:
-        api.set_option("GANET_LGA_WAVE", 1)
-    for a, b in zip(res[1], res[0]):
+        api.set_option("GANET_LGA_WAVE", 2)
+    for a, b in zip(res[2], res[0]):
         assert (a - b).abs().max().item() <= pc.TOL, (a - b).abs().max().item()
-    y, gx, gf = res[1]
+    y, gx, gf = res[2]
     a = (y.double() * gy.double()).sum().item()
     b = (xl.double() * gx.double()).sum().item()
     c = (f.double() * gf.double()).sum().item()
@@ -561,11 +561,11 @@ def test_cost_volume_and_regression_cfg3_cfg5_sizes(api, dev, port_oracle, N, C,
                                    (1, 21, 61, 96)])
 @pytest.mark.parametrize("paired", [0, 1])
 def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape, paired):
-    """GANET_LGA_WG=1|2: the forward / data-backward of API-layout volumes with one LDS ring per 256-thread workgroup (32 x 8
-    tiles; lga_apply_pp_wx / _wxo with a barrier per plane pair, lga_apply_pp_fx / _fxo with progress flags).  Same arithmetic per pixel as the one-wave kernels: results must agree with theirs to fp32
-    rounding on whole tiles, be bit-reproducible over repeated runs (the hand-off between the four waves is one counted wait +
-    one barrier per plane pair: a race would not be deterministic), and agree with the oracle; then once more with the item
-    lists each form chooses for itself."""
+    """GANET_LGA_WAVE=2 (default) against 1 (the fallback): the four forward / data-backward launches of a two-pass chain with one
+    LDS ring per 256-thread workgroup (32 x 8 tiles; lga_apply_pp_wx / _wxo / _wpi, a barrier per plane pair) and with one ring
+    per wave (32 x 2 tiles).  Same arithmetic per pixel: results must agree to fp32 rounding on whole tiles, be bit-reproducible
+    over repeated runs (the hand-off between the four waves is one counted wait + one barrier per plane pair: a race would not
+    be deterministic), and agree with the oracle; then once more with the item lists each form chooses for itself."""
     torch = dev.torch
     B, D, H, W = shape
     g = torch.Generator(device="cuda").manual_seed(sum(shape))
@@ -585,7 +585,7 @@ def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape
             api.set_option("GANET_LGA_MIX", mix)
             api.set_option("GANET_LGA_SEGS", segs)
             for wg in (0, 1, 1):
-                api.set_option("GANET_LGA_WG", wg)
+                api.set_option("GANET_LGA_WAVE", 1 + wg)
                 got = {}
                 chain(api, dev, xn, fn, gyn, 2, 2, want, out=got)
                 if (mix, wg) in res:
@@ -593,7 +593,7 @@ def test_lga_workgroup_ring_matches_default_kernels(api, dev, port_oracle, shape
                 res[mix, wg] = got
                 dev.release()
     finally:
-        api.set_option("GANET_LGA_WG", 1)
+        api.set_option("GANET_LGA_WAVE", 2)
         api.set_option("GANET_LGA_MIX", 1)
         api.set_option("GANET_LGA_SEGS", 0)
     # (bit for bit under the emulator, tests/test_sim_bounds.py; here the two forms are separate instantiations compiled for the

@@ -18,7 +18,7 @@ def sim():
 
 
 @pytest.mark.parametrize("guard", ["end", "start"])
-@pytest.mark.parametrize("wave,segs,mix", [(1, 0, 0), (1, 2, 0), (1, 0, 3), (0, 0, 0)])
+@pytest.mark.parametrize("wave,segs,mix", [(2, 0, 0), (2, 2, 0), (2, 0, 3), (1, 0, 0), (1, 2, 0), (1, 0, 3), (0, 0, 0)])
 def test_lga_depth_sweep_guarded(sim, port_oracle, wave, segs, mix, guard):
     """plane-pair kernels (whole tiles, two depth segments, the mixed item list with three SIMDs assumed) and the tile
     kernels, every depth 1..27"""
@@ -38,7 +38,7 @@ def test_lga_depth_sweep_guarded(sim, port_oracle, wave, segs, mix, guard):
                 err = pc.check_lga_chain(sim, dev, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
                 assert max(err.values()) < 2e-5, (D, B, H, W, err)
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
         sim.set_option("GANET_LGA_SEGS", 0)
         sim.set_option("GANET_LGA_MIX", 1)
 
@@ -185,7 +185,7 @@ def reversed_lanes(sim):
     sim.set_option("HIPSIM_LATE_DMA", 0)
 
 
-@pytest.mark.parametrize("wave,segs", [(1, 0), (1, 2), (0, 0)])
+@pytest.mark.parametrize("wave,segs", [(2, 0), (2, 2), (1, 0), (1, 2), (0, 0)])
 def test_lga_families_with_reversed_thread_order(sim, port_oracle, reversed_lanes, wave, segs):
     dev = pc.NumpyDev()
     sim.set_option("GANET_LGA_WAVE", wave)
@@ -202,7 +202,7 @@ def test_lga_families_with_reversed_thread_order(sim, port_oracle, reversed_lane
             err = pc.check_lga_chain(sim, dev, x, f, gy, 2, 2, {"y": y, "gx": gx, "gf": gf})
             assert max(err.values()) < 2e-5, (shape, err)
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
@@ -213,7 +213,7 @@ def test_sga_with_reversed_thread_order(sim, port_oracle, reversed_lanes, shape)
     pc.check_sga_forward_backward(sim, pc.NumpyDev(), x, gs, go, _sga_want(port_oracle, x, gs, go))
 
 
-# ---- the workgroup-shared ring (GANET_LGA_WG=1: lga_apply_pp_wx / _wxo, four waves on a 32 x 8 tile) ------------------------
+# ---- the workgroup-shared ring (GANET_LGA_WAVE=2: lga_apply_pp_wx / _wxo / _wpi, four waves on a 32 x 8 tile) ------------------------
 # What is new against the one-wave kernels is a hand-off BETWEEN waves: every wave stages a quarter of each ring slot, waits for
 # its own copies (counted) and meets the others at one workgroup barrier per pair-step.  The emulator's wave barrier covers the
 # caller's wavefront only, its copies land as late as the issuing lane's own waits allow, and threads between two barriers run
@@ -223,12 +223,12 @@ _WG_SHAPES = [(1, D, 11, 36) for D in (1, 2, 3, 8, 9, 13, 14, 21, 26, 27)] + \
               (1, 41, 3, 36), (1, 61, 8, 32)]      # (D >= 34: the filter gradient's steady groups of LGAP_WG_NR = 8 steps; 61: two of them)
 
 
-# Both forms: the workgroup rings (GANET_LGA_WG=1, the default since round 5) and the one-wave rings they fall back to (0).
+# Both forms: the workgroup rings (GANET_LGA_WAVE=2, the default since round 5) and the one-wave rings they fall back to (1).
 @pytest.fixture(params=[1, 0], ids=["workgroup-ring", "one-wave-ring"])
 def wg_ring(sim, request):
-    sim.set_option("GANET_LGA_WG", request.param)
+    sim.set_option("GANET_LGA_WAVE", 1 + request.param)
     yield request.param
-    sim.set_option("GANET_LGA_WG", 1)
+    sim.set_option("GANET_LGA_WAVE", 2)
 
 
 @pytest.mark.parametrize("guard", ["end", "start"])
@@ -260,7 +260,7 @@ def test_lga_workgroup_ring_late_landing_guarded(sim, port_oracle, wg_ring, pair
 
 def test_lga_workgroup_ring_is_what_runs(sim, wg_ring):
     """the option reaches the launcher (a test of the one-wave kernels under another name would prove nothing)"""
-    assert sim.get_option("GANET_LGA_WG") == wg_ring
+    assert sim.get_option("GANET_LGA_WAVE") == 1 + wg_ring
 
 
 @pytest.mark.parametrize("paired", [0, 1])
@@ -306,7 +306,7 @@ def test_other_multi_wave_kernels_with_one_wave_running_ahead(sim, port_oracle, 
             err = _planar_chain(sim, port_oracle, shape, 0)
             assert max(err.values()) < 5e-5, (shape, err)
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
     for shape in [(1, 2, 12, 9, 32), (1, 1, 33, 7, 12), (1, 1, 48, 9, 48), (2, 1, 17, 3, 20)]:
         x, gs, go = pc.sga_inputs(shape, seed=sum(shape))
         pc.check_sga_forward_backward(sim, pc.NumpyDev(), x, gs, go, _sga_want(port_oracle, x, gs, go))
@@ -314,7 +314,7 @@ def test_other_multi_wave_kernels_with_one_wave_running_ahead(sim, port_oracle, 
 
 def test_lga_workgroup_ring_loosened_wait_fails(sim, port_oracle):
     """one copy too many left in flight at the per-step wait: the barrier then publishes a slot quarter that has not landed"""
-    assert sim.get_option("GANET_LGA_WG") == 1
+    assert sim.get_option("GANET_LGA_WAVE") == 2
     sim.set_option("HIPSIM_LATE_DMA", 1)
     sim.set_option("HIPSIM_VMCNT_SLACK", 1)
     try:
@@ -345,14 +345,14 @@ def test_lga_workgroup_ring_bit_identical_to_one_wave_kernels(sim, port_oracle, 
             gy = rng.standard_normal(shape).astype(np.float32)
             res = []
             for wg in (0, 1):
-                sim.set_option("GANET_LGA_WG", wg)
+                sim.set_option("GANET_LGA_WAVE", 1 + wg)
                 got = {}
                 (pc.check_lga2_paired if paired else pc.check_lga_chain)(sim, pc.NumpyDev(), x, f, gy, 2, 2, None, out=got)
                 res.append(got)
             for k in res[0]:
                 assert np.array_equal(res[0][k], res[1][k]), (shape, k)
     finally:
-        sim.set_option("GANET_LGA_WG", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
         sim.set_option("GANET_LGA_MIX", 1)
         sim.set_option("GANET_LGA_SEGS", 0)
 

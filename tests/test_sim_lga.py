@@ -67,7 +67,7 @@ def test_lga_kernel_families_and_depth_segments(sim, port_oracle, shape, r, wave
         err = pc.check_lga_chain(sim, DEV, x, f, gy, r, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
@@ -137,13 +137,13 @@ def test_plane_pair_apply_long_marches(sim, port_oracle, shape, segs):
     gy = rng.standard_normal(shape).astype(np.float32)
     y = port_oracle.lga_forward(x, f, 2)
     gx, gf = port_oracle.lga_backward(x, f, gy, 2)
-    sim.set_option("GANET_LGA_WAVE", 1)
+    sim.set_option("GANET_LGA_WAVE", 2)
     sim.set_option("GANET_LGA_SEGS", segs)
     try:
         err = pc.check_lga_chain(sim, DEV, x, f, gy, 2, 1, {"y": y, "gx": gx, "gf": gf})
         assert max(err.values()) < 2e-5, err
     finally:
-        sim.set_option("GANET_LGA_WAVE", 1)
+        sim.set_option("GANET_LGA_WAVE", 2)
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
