@@ -87,3 +87,14 @@ for name, fn in (("forward scans", fwd), ("adjoint scans", bwd)):
         return g
     g2 = two([(0, 2), (1, 3)])
     print(name, "two at a time (column beside row) %.4f ms" % sorted(timeit(g2) for _ in range(3))[1], flush=True)
+    # round 5: the row scans are bound by what a SIMD can issue (time follows the waves on the fullest SIMD: 2,560 rows on 1,024
+    # SIMDs = 3 rounds for 2.5), so the two row scans side by side (5,120 waves = 5 per SIMD, balanced) could save a round of six;
+    # likewise the two column scans (832 workgroups = 3.25 per CU instead of 2 x 1.625 -> 2 x 2)
+    g3 = two([(2, 3)])
+    gseq_rows = capture(fn, False, order=(2, 3))
+    print(name, "rows only: sequential %.4f ms   right beside left %.4f ms" % (sorted(timeit(gseq_rows) for _ in range(3))[1], sorted(timeit(g3) for _ in range(3))[1]), flush=True)
+    g4 = two([(0, 1)])
+    gseq_cols = capture(fn, False, order=(0, 1))
+    print(name, "columns only: sequential %.4f ms   down beside up %.4f ms" % (sorted(timeit(gseq_cols) for _ in range(3))[1], sorted(timeit(g4) for _ in range(3))[1]), flush=True)
+    g5 = two([(0, 1), (2, 3)])
+    print(name, "all four: (down beside up) then (right beside left) %.4f ms" % sorted(timeit(g5) for _ in range(3))[1], flush=True)
