@@ -122,7 +122,11 @@ int ganet_sga_backward(const float *x, const float *g0, const float *g1, const f
                        float *gw2, float *gw3, int N, int C, int D, int H, int W, void *stream);
 
 /* The last step of ganet_sga_backward on its own: every gradient from the four adjoint volumes in G_ws (written by
- * ganet_sga_backward_scan_ws) and the forward volumes in A_ws.  ganet_sga_backward == 4 x ganet_sga_backward_scan_ws + this.
+ * ganet_sga_backward_scan_ws, in the layout ganet_sga_workspace_layout reports for these dimensions -- NOT by
+ * ganet_sga_backward_scan, whose G has the API layout) and the forward volumes in A_ws.  On 16-byte aligned volumes
+ * ganet_sga_backward == 4 x ganet_sga_backward_scan_ws + this; ganet_sga_backward itself also accepts a contiguous gradient /
+ * guidance at a 4-byte aligned address (it then keeps the API layout internally), the _ws entries return GANET_E_UNSUPPORTED
+ * for that on a tiled shape.
  * Replaces: the bottom_diff part of sga_*_data_backward (:182-207 & mirrors) + sga_*_weight_backward (:210-281 & mirrors). */
 int ganet_sga_backward_point(const float *x, const float *g0, const float *g1, const float *g2, const float *g3,
                              const float *A_ws, const float *G_ws, float *grad_x, float *gw0, float *gw1,
