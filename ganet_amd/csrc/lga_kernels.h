@@ -807,7 +807,7 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #include "lga_apply_pp.inc"
 
 
-// API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WG)
+// API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WAVE = 2)
 #define GA_PP_NAME lga_apply_pp_wx
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
@@ -840,7 +840,7 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_Y(d) GA_PP_Y_PAIRED(d)
 #include "lga_apply_pp.inc"
 
-// the same with ONE planar ring per 256-thread workgroup (GANET_LGA_WG)
+// the same with ONE planar ring per 256-thread workgroup (GANET_LGA_WAVE = 2)
 #define GA_PP_NAME lga_apply_pp_wxo
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
@@ -860,7 +860,7 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-// the same through ONE ring per 256-thread workgroup (GANET_LGA_WG)
+// the same through ONE ring per 256-thread workgroup (GANET_LGA_WAVE = 2)
 #define GA_PP_NAME lga_apply_pp_wpi
 #define GA_PP_SEG_T LgaSegMix
 #define GA_PP_DECODE lga_decode_item_mix
