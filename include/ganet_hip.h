@@ -288,6 +288,9 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *   GANET_SGA_WIDE_COL=0|1|2  vertical scans on LDS-staged column blocks with one wavefront per column (1,024-thread blocks,
  *                         D <= 192): never | for inputs with few column blocks and D >= 96 (default; measured on
  *                         [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40) | whenever the kernel applies (tests)
+ *   GANET_SGA_TILED = 0|1 ganet_sga_backward's private workspace: the vertical directions' adjoint volumes G_down / G_up in the API
+ *                         layout | tiled [slice][W/16][H/4][D][4][16] where W % 16 == 0, H % 4 == 0 and the 16-column kernels run
+ *                         (default; whole step -1.1 %; see ganet_sga_workspace_layout)
  *   GANET_LGA_WAVE=0|1|2  LGA kernel family (radius <= 2): 256-thread tiles (any radius; the general fallback) | wave-autonomous
  *                         plane-pair kernels, LDS-DMA staging, FMAs packed along plane pairs, one ring per wave on 32 x 2 pixel
  *                         tiles | the same with the forward / data-backward kernels on ONE ring per 256-thread workgroup (32 x 8

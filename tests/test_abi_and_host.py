@@ -151,3 +151,49 @@ def test_bench_roofline_object_from_stage_times():
     kern = {"sga_bwd_point<4, false, true>": {"read_bytes": 7, "write_bytes": 1}, "sga_bwd_point<4, false>": {"read_bytes": 10, "write_bytes": 5}}
     assert bench._family_traffic("sga_bwd_point", kern) == 8
     assert bench._family_traffic("sga_merge_argmax", kern) is None
+
+
+def test_option_table(built_lib):
+    """include/ganet_hip.h's knob table as the library implements it (no GPU involved): eight options, the LGA family selector is
+    0 | 1 | 2 with the workgroup rings as the default, names retired in ABI 7 / 10 are accepted and change nothing, unknown names
+    are GANET_E_INVALID."""
+    lib = ctypes.CDLL(built_lib)
+    lib.ganet_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.ganet_get_option.argtypes = [ctypes.c_char_p]
+    names = [b"GANET_SGA_TILED", b"GANET_LGA_WAVE", b"GANET_LGA_MIX", b"GANET_LGA_SEGS", b"GANET_SGA_WIDE_COL", b"GANET_SGA_WIDE_SCAN",
+             b"GANET_SGA_ROWWAVE", b"GANET_SGA_COLBLOCK"]
+    defaults = {n: lib.ganet_get_option(n) for n in names}
+    assert all(v >= 0 for v in defaults.values()), defaults
+    if "GANET_LGA_WAVE" not in os.environ:
+        assert defaults[b"GANET_LGA_WAVE"] == 2
+    hdr = open(os.path.join(ROOT, "include", "ganet_hip.h")).read()
+    for n in names:
+        assert n.decode() in hdr, n
+    try:
+        for v, want in ((0, 0), (1, 1), (2, 2), (7, 2), (-3, 0)):
+            assert lib.ganet_set_option(b"GANET_LGA_WAVE", v) == 0 and lib.ganet_get_option(b"GANET_LGA_WAVE") == want
+        before = {n: lib.ganet_get_option(n) for n in names}
+        for retired in (b"GANET_LGA_WG", b"GANET_SGA_POINT_Q4", b"GANET_SGA_STREAMS", b"GANET_LGA_SPLIT"):
+            assert lib.ganet_set_option(retired, 1) == 0
+            assert lib.ganet_get_option(retired) < 0
+        assert {n: lib.ganet_get_option(n) for n in names} == before
+        assert lib.ganet_set_option(b"GANET_NO_SUCH_OPTION", 1) == -1 and lib.ganet_get_option(b"GANET_NO_SUCH_OPTION") == -1
+    finally:
+        for n, v in defaults.items():
+            lib.ganet_set_option(n, v)
+
+
+def test_traffic_file_names_the_tree_it_was_measured_on():
+    """profiles/traffic_pmc.json carries the hash of ganet_amd/csrc/ it was measured on (scripts/pmc_traffic.py) and bench.py
+    compares it with this tree's: the committed file must describe the committed kernels, and the hash must
+    follow the sources."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.pmc_traffic() is not None
+    assert bench.pmc_traffic_tree() == bench.csrc_tree_hash(), \
+        "profiles/traffic_pmc.json was measured on other kernel sources: regenerate it (scripts/gpu_s3.sh) or say why not"
+    r = bench.roofline_from_stages({"sga_scan_fwd_down": 0.07, "sga_scan_fwd_up": 0.07, "sga_scan_fwd_right": 0.07, "sga_scan_fwd_left": 0.07,
+                                    "sga_merge_argmax": 0.11, "sga_bwd_scan_down": 0.08, "sga_bwd_scan_up": 0.08, "sga_bwd_scan_right": 0.07,
+                                    "sga_bwd_scan_left": 0.07, "sga_bwd_point": 0.29, "lga_fwd_pass": 0.09, "lga_bwd_pass": 0.19})
+    assert r["traffic_tree_matches"] is True and r["unit_traffic_ratio"] > 1.0
+    assert all(f["traffic"] is not None for f in r["families"]), "a family's kernels are missing from the traffic file"
