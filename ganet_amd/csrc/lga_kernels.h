@@ -35,10 +35,7 @@
 namespace ga {
 
 constexpr int LGA_TW = 32;   // tile width  (pixels, = lanes along W)
-#ifndef GA_LGA_TH
-#define GA_LGA_TH 8
-#endif
-constexpr int LGA_TH = GA_LGA_TH;    // tile height
+constexpr int LGA_TH = 8;    // tile height (2 / 4 / 12 / 16 measured slower, profiles/HISTORY.md)
 constexpr int LGA_NT = LGA_TW * LGA_TH;   // threads per block of the tile kernels
 constexpr int LGA_PB = 4;    // planes per LDS stage
 #ifndef LGA_WAVES_PER_SIMD
@@ -334,25 +331,10 @@ constexpr int LGAW_TH = 2;       // pixel rows per wave (lanes = LGA_TW x LGAW_T
 #define LGAW_LA 2                // row steps of LDS lookahead
 #endif
 
-// Work items of the plane-pair forward / data-backward = tiles x nseg equal depth segments of seg_len planes, segment fastest
-// in the item order.
+// Work items of the filter gradient = whole tiles (nseg = 1, seg_len = D; the forward / data-backward use LgaSegMix below).
 struct LgaSeg {
   int nseg, seg_len, tiles_x, tiles_y;
 };
-
-// item -> (tile bx, by, batch b, depth range); each XCD (block id % 8) gets a contiguous band of tiles
-GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, int &d_lo, int &d_hi)
-{
-  int item = xcd_remap(blockIdx.x, gridDim.x);        // segment fastest: the segments of a tile read the same filter lines
-  const int seg = item % sg.nseg;
-  item /= sg.nseg;
-  d_lo = seg * sg.seg_len;
-  d_hi = d_lo + sg.seg_len < D ? d_lo + sg.seg_len : D;
-  bx = item % sg.tiles_x; item /= sg.tiles_x;
-  by = item % sg.tiles_y;
-  b = item / sg.tiles_y;
-}
-
 
 // Emulator hooks of the LDS-DMA kernels.  hipcc does not count an asm global -> LDS copy, so their waits are explicit
 // (GA_VMCNT) and derived from the fixed issue order; GA_DMA_MASKED(n): this lane sits out n copy instructions its wave
@@ -367,7 +349,6 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #define GA_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define GA_DMA_MASKED(n) ((void)0)
 #endif
-
 
 // ---- wave-autonomous forward / data-backward, PLANE-PAIR packing ----------------------------------------
 // Packing the FMAs along the window's COLUMNS (round 1's kernels, removed) costs a 5-wide window three aligned register pairs,
@@ -393,9 +374,7 @@ GA_DEV void lga_decode_item(const LgaSeg &sg, int D, int &bx, int &by, int &b, i
 #ifndef LGAP_WG_NR
 #define LGAP_WG_NR 8      // ring slots (4 KB each) of the workgroup-shared ring: 34 KB per workgroup, three workgroups per CU (see the march of lga_apply_pp.inc)
 #endif
-#ifndef LGAP_ROW_ASM
 #define LGAP_ROW_ASM 1           // radius 2: a window row's 15 packed FMAs as one asm statement (lga_row_fma); 0 = one statement per FMA
-#endif
 // Two dwords of one LDS row pair in ONE instruction, into a register pair: p[O0] and p[O1] (dword offsets, at most 255).  The
 // planar staging of lga_apply_pp.inc (GA_PP_IN = 2) keeps the two planes of a pair LGA_TW + 8 dwords apart; written as two
 // loads hipcc pairs up neighbouring COLUMNS instead and assembles the plane pairs with 32 v_mov per plane pair.  The asm is
@@ -439,37 +418,13 @@ template <int R> struct LgaPCfg {
 // M0 holds the LDS base of an LDS-DMA copy.  It is a RESERVED register: hipcc never allocates it, and the only code of its own
 // that reads it (LDS-DMA builtins, s_movrel / dynamic register indexing, GWS, s_sendmsg) sets it immediately before the use, so
 // a kernel without such constructs need not preserve it around the hand-written copies.  scripts/isa_loop_check.py asserts
-// that no instruction outside the copy batches touches m0 in these kernels.  GA_M0_SAVE = 1 restores the save / restore pair
-// (two scalar instructions per batch; the march is bound by its instruction count, profiles/r5c_* ... r5f_*).
+// that no instruction outside the copy batches touches m0 in these kernels (a save / restore pair around every
+// batch cost two scalar instructions; the march is bound by its instruction count, profiles/r5c_* ... r5f_*).
 // ("m0" in the clobber lists instead, ADVICE r4: hipcc answers "inline asm clobber list contains reserved registers: M0 ... clobbering
 // them may lead to undefined behaviour" -- for a reserved register the list is not the contract; the ISA check above is.)
-#ifndef GA_M0_SAVE
-#define GA_M0_SAVE 0
-#endif
-#if GA_M0_SAVE
-#define GA_M0_SAVE_ASM "s_mov_b32 %0, m0\n\t"
-#define GA_M0_RESTORE_ASM "\n\ts_mov_b32 m0, %0"
-#define GA_M0_RESTORE_TAIL "s_mov_b32 m0, %0"
-#else
 #define GA_M0_SAVE_ASM "; (m0 not preserved) %0\n\t"
 #define GA_M0_RESTORE_ASM ""
 #define GA_M0_RESTORE_TAIL ""
-#endif
-
-// one 4-byte global -> LDS copy per lane, 64-bit per-lane address: lane l's dword lands at slot + 4 * l
-GA_DEV void lga_dma4p(const float *gsrc, float *slot, int lane)
-{
-#if defined(GA_HIPSIM)
-  hipsim::dma_issue(slot + lane, gsrc, 1);
-#else
-  (void)lane;
-  __builtin_assume(slot != nullptr);      // (a generic -> LDS address cast otherwise carries a null test: two scalar instructions per batch)
-  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) float *)slot;
-  unsigned keep;
-  asm volatile(GA_M0_SAVE_ASM "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" GA_M0_RESTORE_ASM
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
-}
 
 // acc += X * (w, w) with w = the LOW / HIGH half of the register pair W: op_sel picks the half for both results, so 2 n
 // loop-invariant weights live in n register pairs (written as fma2(X, mk2(w, w), acc) the optimiser hoists the splat out of
@@ -591,8 +546,8 @@ GA_DEV void lga_row_fma(f2 &e1, f2 &p1, f2 &c1, f2 &e2, f2 &p2, f2 &c2, const f2
 }
 
 // all ND copies of one plane pair: copy k moves lane l's dword from base + off[k] (bytes) to slot + 256 k + 4 l, scalar base +
-// 32-bit lane offset (the offsets are the same for every pair, only the base moves).  M0 holds the LDS base of the batch and
-// is saved / restored around it (a write to M0 needs one wait state before the copy that uses it).
+// 32-bit lane offset (the offsets are the same for every pair, only the base moves).  M0 holds the LDS base of the batch
+// (a write to M0 needs one wait state before the copy that uses it).
 // LGAP_IMM_OFFSET = 1: the instruction's immediate offset is added to BOTH addresses of an LDS-DMA copy (global and LDS), so
 // ONE M0 value serves the whole batch: copy k carries offset:256 k and its lane offsets are stored 256 k lower (the caller
 // passes `base` LGAP_BIAS bytes low and offsets LGAP_BIAS bytes high so that they stay non-negative) -- ND + 4 instructions
@@ -805,7 +760,6 @@ GA_DEV void lga_decode_item_mix(const LgaSegMix &sg, int D, int &bx, int &by, in
 #define GA_PP_NDC 2
 #define GA_PP_Y(d) yb[(i64)(d) * geo.HW + pix]
 #include "lga_apply_pp.inc"
-
 
 // API layout in and out, ONE planar ring per 256-thread workgroup (32 x 8 tile, W % 4 == 0, 16-byte aligned x; radius 2; GANET_LGA_WAVE = 2)
 #define GA_PP_NAME lga_apply_pp_wx

@@ -1,6 +1,6 @@
 """Static check of the hand-counted-vmcnt kernels: inside the main loop of each LDS-DMA kernel the compiler must not have added
 vector-memory operations of its own (register spills = scratch_load / scratch_store count in vmcnt and would silently break the
-explicit s_waitcnt vmcnt(n) bookkeeping).  Also: the copy batches set M0 without saving it (lga_kernels.h: GA_M0_SAVE), which is
+explicit s_waitcnt vmcnt(n) bookkeeping).  Also: the copy batches set M0 without saving it (lga_kernels.h: GA_M0_SAVE_ASM), which is
 only sound while nothing else in the kernel reads or writes M0 -- every mention of m0 must be one of the batches' own
 `s_mov_b32 m0, <sgpr>` / `s_add_u32 m0, m0, ...`.  python scripts/isa_loop_check.py [asm file]   (no GPU needed; exits 1 on a finding)"""
 import os, re, subprocess, sys, tempfile
