@@ -295,7 +295,7 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *                         plane-pair kernels, LDS-DMA staging, FMAs packed along plane pairs, one ring per wave on 32 x 2 pixel
  *                         tiles | the same with the forward / data-backward kernels on ONE ring per 256-thread workgroup (32 x 8
  *                         tiles: the halo'd tile staged once for four waves, 12 rows fetched for 8 instead of 24; a barrier per
- *                         plane pair).  Default 2 (whole step -1.4 ... -3.5 % over five boxes against 1, profiles/r8*_ab_step*).
+ *                         plane pair).  Default 2 (whole step -1.4 ... -3.5 % in five A/Bs on four boxes against 1, profiles/r8*_ab_step*).
  *                         The filter gradient runs one ring per wave in both (its workgroup form: measured, no gain, removed)
  *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
  *   GANET_LGA_MIX=0|1|n   the same kernels with a MIXED item list: whole tiles first (a whole number per SIMD), the remaining
