@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libganet_hip.so"
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -56,6 +56,8 @@ _PROTOS = {
     "ganet_softmin_regression_backward": [_P] * 6 + [_I] * 4 + [_P],
     "ganet_trilinear_upsample_forward": [_P] * 2 + [_I] * 7 + [_P],
     "ganet_trilinear_upsample_backward": [_P] * 2 + [_I] * 7 + [_P],
+    "ganet_residual_relu_forward": [_P] * 5 + [_I] * 5 + [_P],
+    "ganet_residual_relu_backward": [_P] * 5 + [_I] * 5 + [_P],
     "ganet_selftest_dpp": [_P, _P, _P],
     "ganet_selftest_dpp_wave": [_P, _P, _P],
 }

@@ -1392,6 +1392,57 @@ GA_EXPORT int ganet_softmin_regression_backward(const float *x, const float *out
   return check_launch("softmin regression backward");
 }
 
+// ---- SGABlock's residual epilogue (models/GANet_deep.py:270-277) --------------------
+namespace {
+int check_residual(const char *who, int N, int C, int D, int H, int W)
+{
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return fail(GANET_E_INVALID, "%s: non-positive size N=%d C=%d D=%d H=%d W=%d", who, N, C, D, H, W);
+  return GANET_OK;
+}
+// x: enough 256-thread blocks per slice to fill the chip about four times over, y: the slices
+dim3 residual_grid(i64 S, i64 per_slice)
+{
+  i64 gx = (per_slice + 255) / 256;
+  const i64 want = (256 * 16 + S - 1) / S;
+  if (gx > want) gx = want;
+  if (gx < 1) gx = 1;
+  return dim3((unsigned)gx, (unsigned)(S < 65535 ? S : 65535));
+}
+}  // namespace
+
+GA_EXPORT int ganet_residual_relu_forward(const float *t, const float *rem, const float *bn_scale, const float *bn_shift,
+                                          float *y, int N, int C, int D, int H, int W, void *stream)
+{
+  GA_TRY(check_residual("ganet_residual_relu_forward", N, C, D, H, W));
+  if (!t || !rem || !y) return fail(GANET_E_INVALID, "ganet_residual_relu_forward: null pointer");
+  if ((bn_scale == nullptr) != (bn_shift == nullptr))
+    return fail(GANET_E_INVALID, "ganet_residual_relu_forward: bn_scale and bn_shift come together");
+  const i64 S = (i64)N * C, slice = (i64)D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (slice % 4 == 0 && aligned16(t) && aligned16(rem) && aligned16(y))
+    GA_LAUNCH((residual_relu_fwd<true>), residual_grid(S, slice / 4), dim3(256), st, t, rem, bn_scale, bn_shift, y, S, C, slice);
+  else
+    GA_LAUNCH((residual_relu_fwd<false>), residual_grid(S, slice), dim3(256), st, t, rem, bn_scale, bn_shift, y, S, C, slice);
+  return check_launch("residual + relu forward");
+}
+
+GA_EXPORT int ganet_residual_relu_backward(const float *y, const float *grad_y, const float *bn_scale, float *grad_t,
+                                           float *grad_rem, int N, int C, int D, int H, int W, void *stream)
+{
+  GA_TRY(check_residual("ganet_residual_relu_backward", N, C, D, H, W));
+  if (!y || !grad_y || !grad_rem) return fail(GANET_E_INVALID, "ganet_residual_relu_backward: null pointer");
+  if (bn_scale && !grad_t)
+    return fail(GANET_E_INVALID, "ganet_residual_relu_backward: a scaled gradient needs a buffer of its own (grad_t)");
+  const i64 S = (i64)N * C, slice = (i64)D * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (slice % 4 == 0 && aligned16(y) && aligned16(grad_y) && aligned16(grad_rem) && aligned16(grad_t))
+    GA_LAUNCH((residual_relu_bwd<true>), residual_grid(S, slice / 4), dim3(256), st, y, grad_y, bn_scale, grad_t, grad_rem, S, C, slice);
+  else
+    GA_LAUNCH((residual_relu_bwd<false>), residual_grid(S, slice), dim3(256), st, y, grad_y, bn_scale, grad_t, grad_rem, S, C, slice);
+  return check_launch("residual + relu backward");
+}
+
 GA_EXPORT int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream)
 {
   if (!scratch_dev || !host_out) return fail(GANET_E_INVALID, "ganet_selftest_dpp_wave: null pointer");

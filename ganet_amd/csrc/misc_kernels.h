@@ -582,6 +582,74 @@ softmin_regression_bwd(const float *__restrict__ x, const float *__restrict__ ou
   }
 }
 
+// ---- SGABlock's residual epilogue (models/GANet_deep.py:270-277) -----------------------------------------
+// Behind `conv_refine` (Conv3d + BatchNorm3d, no ReLU) the block ends with `x += rem; relu(x)`: per element
+//   y = max(scale[c] * t + shift[c] + rem, 0)      t = the convolution's output, (scale, shift) = the BatchNorm3d folded from
+//                                                  its running statistics (eval mode);  scale == nullptr: y = max(t + rem, 0)
+//                                                  on t = bn(conv) as PyTorch computed it (training mode).
+// Stock PyTorch: batch_norm (r V, w V) + add_ (r 2V, w V) + relu_ (r V, w V) = 7 V; here 2 V in, 1 V out.  y may BE t (the
+// reference adds in place as well), which is why neither carries __restrict__.  blockIdx.y = slice (n, c): no division per element.
+GA_DEV float relu_keep_nan(float v) { return v <= 0.f ? 0.f : v; }      // ATen's relu / threshold_backward: a NaN passes through
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+residual_relu_fwd(const float *t, const float *__restrict__ rem, const float *__restrict__ scale,
+                  const float *__restrict__ shift, float *y, i64 S /* N*C */, int C, i64 slice /* D*H*W */)
+{
+  const i64 stride = (i64)gridDim.x * blockDim.x, first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  for (i64 s = blockIdx.y; s < S; s += gridDim.y) {
+    float sc = 1.f, sh = 0.f;
+    if (scale) { const int ch = (int)(s % C); sc = scale[ch]; sh = shift[ch]; }
+    const i64 base = s * slice;
+    if (VEC4) {
+      for (i64 i = first; i < (slice >> 2); i += stride) {
+        const i64 e = base + (i << 2);
+        const f4 a = *reinterpret_cast<const f4 *>(t + e), r = *reinterpret_cast<const f4 *>(rem + e);
+        f4 o;
+        o.x = relu_keep_nan(fmaf(a.x, sc, sh) + r.x); o.y = relu_keep_nan(fmaf(a.y, sc, sh) + r.y);
+        o.z = relu_keep_nan(fmaf(a.z, sc, sh) + r.z); o.w = relu_keep_nan(fmaf(a.w, sc, sh) + r.w);
+        *reinterpret_cast<f4 *>(y + e) = o;
+      }
+    } else {
+      for (i64 i = first; i < slice; i += stride)
+        y[base + i] = relu_keep_nan(fmaf(t[base + i], sc, sh) + rem[base + i]);
+    }
+  }
+}
+
+// adjoint: g = [y <= 0] ? 0 : gy (what relu_'s threshold_backward computes from the saved output);  g_rem = g;
+// g_t = scale[c] * g (scale == nullptr: g_t = g; g_t == nullptr: not written -- the caller hands g_rem to both inputs)
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+residual_relu_bwd(const float *__restrict__ y, const float *__restrict__ gy, const float *__restrict__ scale,
+                  float *__restrict__ g_t, float *__restrict__ g_rem, i64 S, int C, i64 slice)
+{
+  const i64 stride = (i64)gridDim.x * blockDim.x, first = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  for (i64 s = blockIdx.y; s < S; s += gridDim.y) {
+    const float sc = scale ? scale[(int)(s % C)] : 1.f;
+    const i64 base = s * slice;
+    if (VEC4) {
+      for (i64 i = first; i < (slice >> 2); i += stride) {
+        const i64 e = base + (i << 2);
+        const f4 v = *reinterpret_cast<const f4 *>(y + e), g = *reinterpret_cast<const f4 *>(gy + e);
+        f4 o;
+        o.x = v.x <= 0.f ? 0.f : g.x; o.y = v.y <= 0.f ? 0.f : g.y;
+        o.z = v.z <= 0.f ? 0.f : g.z; o.w = v.w <= 0.f ? 0.f : g.w;
+        *reinterpret_cast<f4 *>(g_rem + e) = o;
+        if (g_t) {
+          o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
+          *reinterpret_cast<f4 *>(g_t + e) = o;
+        }
+      }
+    } else {
+      for (i64 i = first; i < slice; i += stride) {
+        const float g = y[base + i] <= 0.f ? 0.f : gy[base + i];
+        g_rem[base + i] = g;
+        if (g_t) g_t[base + i] = g * sc;
+      }
+    }
+  }
+}
+
 // ---- trilinear up-sampling of a volume (Disp / DispAgg.forward, models/GANet_deep.py:212, 240) -----------------------------
 // y = F.interpolate(x, size=[Do, Ho, Wo], mode='trilinear', align_corners=False) on [S, Di, Hi, Wi] -> [S, Do, Ho, Wo]
 // (S = N * C slices).  Per axis, PyTorch's rule (area_pixel_compute_source_index): src = max(scale * (o + 0.5) - 0.5, 0)

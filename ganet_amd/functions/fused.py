@@ -14,7 +14,8 @@ from .. import _native
 from .GANet import _check, _p, _sga_infer, _stream
 
 __all__ = ["L1NormalizeGroupsFunction", "NormDisparityRegressionFunction", "normalize_guidance", "normalize_filters",
-           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction", "LgaRegressFunction"]
+           "sga_forward_infer", "SoftminFunction", "SoftminDisparityRegressionFunction", "TrilinearUpsampleFunction", "LgaRegressFunction",
+           "ResidualReluFunction"]
 
 
 def _lib():
@@ -255,3 +256,55 @@ class LgaRegressFunction(Function):
             gf = torch.empty_like(filters)
             _lib().call("ganet_lga_backward", _p(x), _p(filters), _p(gy), _p(gx), _p(gf), N, D, H, W, ctx.radius, 0, _stream())
         return gx, gf, None, None
+
+
+class ResidualReluFunction(Function):
+    """The end of SGABlock.forward (models/GANet_deep.py:270-277) in one pass each way:
+        y = relu(bn_scale[c] * t + bn_shift[c] + rem)      bn_scale / bn_shift: conv_refine's BatchNorm3d folded from its running
+                                                           statistics (eval mode; constants: they get no gradient here)
+        y = relu(t + rem)                                  bn_scale is None: t = bn(conv(..)) from the framework (training mode)
+    for `x = conv_refine(x); x += rem; return relu(x)`.  `inplace` writes y over t as the reference's `x += rem` does (t must
+    be a temporary nobody else needs: the convolution's / BatchNorm's output -- BatchNorm's backward reads its input, not t).
+    Backward: g = grad_y where y > 0; both inputs take g (bn_scale given: t takes bn_scale[c] * g)."""
+
+    @staticmethod
+    def forward(ctx, t, rem, bn_scale=None, bn_shift=None, inplace=False):
+        ts = [t, rem] + ([bn_scale, bn_shift] if bn_scale is not None else [])
+        _check(*ts)
+        if t.dim() != 5 or t.shape != rem.shape:
+            raise ValueError(f"expected two [N,C,D,H,W] volumes of one shape, got {tuple(t.shape)} and {tuple(rem.shape)}")
+        N, C, D, H, W = t.shape
+        if (bn_scale is None) != (bn_shift is None):
+            raise ValueError("bn_scale and bn_shift come together")
+        if bn_scale is not None and (bn_scale.numel() != C or bn_shift.numel() != C):
+            raise ValueError("bn_scale / bn_shift must have one entry per channel")
+        ctx.dims = (N, C, D, H, W)
+        with torch.cuda.device_of(t):
+            y = t if inplace else torch.empty_like(t)
+            _lib().call("ganet_residual_relu_forward", _p(t), _p(rem), _p(bn_scale) if bn_scale is not None else None,
+                        _p(bn_shift) if bn_shift is not None else None, _p(y), N, C, D, H, W, _stream())
+        if inplace:
+            ctx.mark_dirty(t)
+        ctx.scaled = bn_scale is not None
+        if ctx.scaled:
+            ctx.save_for_backward(y, bn_scale)
+        else:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        y = ctx.saved_tensors[0]
+        g = grad_y.contiguous()
+        _check(g)
+        N, C, D, H, W = ctx.dims
+        with torch.cuda.device_of(g):
+            g_rem = torch.empty_like(y)
+            if ctx.scaled:
+                g_t = torch.empty_like(y)
+                _lib().call("ganet_residual_relu_backward", _p(y), _p(g), _p(ctx.saved_tensors[1]), _p(g_t), _p(g_rem),
+                            N, C, D, H, W, _stream())
+            else:
+                g_t = g_rem
+                _lib().call("ganet_residual_relu_backward", _p(y), _p(g), None, None, _p(g_rem), N, C, D, H, W, _stream())
+        return g_t, g_rem, None, None, None

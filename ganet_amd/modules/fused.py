@@ -3,13 +3,25 @@ reference-compatible modules in ganet_amd.modules.GANet are unchanged."""
 import torch
 from torch.nn.modules.module import Module
 
-from ..functions.fused import (LgaRegressFunction, NormDisparityRegressionFunction, SoftminDisparityRegressionFunction,
-                               SoftminFunction, TrilinearUpsampleFunction, normalize_filters, normalize_guidance,
-                               sga_forward_infer)
+from ..functions.fused import (LgaRegressFunction, NormDisparityRegressionFunction, ResidualReluFunction,
+                               SoftminDisparityRegressionFunction, SoftminFunction, TrilinearUpsampleFunction,
+                               normalize_filters, normalize_guidance, sga_forward_infer)
 from ..functions.GANet import Lga2Function, LgaFunction, SgaFunction
 
 __all__ = ["GuidedSGA", "GuidedSGABnRelu", "NormalizedLGA2", "NormDisparityRegression", "SoftminDisparityRegression",
-           "DispAggTail", "TrilinearUpsample"]
+           "DispAggTail", "TrilinearUpsample", "ResidualBnRelu", "folded_bn"]
+
+
+def folded_bn(bn):
+    """(scale, shift) with bn(x) == scale[c] * x + shift[c] for a BatchNorm in eval mode (running statistics)."""
+    with torch.no_grad():
+        scale = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.affine:
+            scale = scale * bn.weight
+            shift = bn.bias - bn.running_mean * scale
+        else:
+            shift = -bn.running_mean * scale
+        return scale.float().contiguous(), shift.float().contiguous()
 
 
 class GuidedSGA(Module):
@@ -34,14 +46,35 @@ class GuidedSGABnRelu(Module):
         ks = normalize_guidance(g, x.shape[1])
         if self.training or torch.is_grad_enabled() or not self.bn.track_running_stats:
             return torch.relu(self.bn(SgaFunction.apply(x, *ks)))
+        return sga_forward_infer(x, *ks, *folded_bn(self.bn))
+
+
+class ResidualBnRelu(Module):
+    """The end of SGABlock.forward (models/GANet_deep.py:270-277): forward(t, rem) == relu(bn(t) + rem) for
+    `x = conv_refine(x); x += rem; return relu(x)`, where conv_refine = Conv3d + `bn` (BasicConv(relu=False), :238) and the
+    caller passes t = conv_refine.conv(x).  (refine=False blocks, :273: t = the SGA output, bn = the block's own `bn`.)
+
+    Eval mode with frozen statistics: the BatchNorm is folded into a per-channel affine and the whole tail is ONE pass over the
+    volumes (stock PyTorch: batch_norm + add_ + relu_ = 7 volume passes, here 3); its backward hands g = grad * [y > 0] to
+    `rem` and bn_scale[c] * g to t.  Training mode, or a BatchNorm whose parameters want gradients: `bn` runs in the framework
+    (batch statistics, running-stat updates, SyncBatchNorm's collectives all stay what they were) and add + ReLU are fused."""
+
+    def __init__(self, bn, inplace=True):
+        super().__init__()
+        self.bn = bn                      # the block's BatchNorm3d (shared, not copied)
+        self.inplace = inplace            # y overwrites t, as the reference's `x += rem` does (t: the convolution's output)
+
+    def forward(self, t, rem):
         bn = self.bn
-        scale = torch.rsqrt(bn.running_var + bn.eps)
-        if bn.affine:
-            scale = scale * bn.weight
-            shift = bn.bias - bn.running_mean * scale
-        else:
-            shift = -bn.running_mean * scale
-        return sga_forward_infer(x, *ks, scale.float().contiguous(), shift.float().contiguous())
+        frozen = (not bn.training and bn.track_running_stats and
+                  not (torch.is_grad_enabled() and any(p.requires_grad for p in bn.parameters())))
+        t, rem = t.contiguous(), rem.contiguous()
+        if frozen:
+            # autograd refuses an in-place write to a leaf that wants a gradient; anything else (a convolution's output: its
+            # backward does not read it) may be overwritten
+            inplace = self.inplace and not (torch.is_grad_enabled() and t.requires_grad and t.is_leaf)
+            return ResidualReluFunction.apply(t, rem, *folded_bn(bn), inplace)
+        return ResidualReluFunction.apply(bn(t), rem, None, None, True)     # bn(t) is a temporary of this call: always in place
 
 
 class NormalizedLGA2(Module):

@@ -2,7 +2,9 @@
 model, without touching its parameters or state_dict keys: the three call-site edits of INTEGRATION.md done by
 rebinding `forward` on the SGABlock / DispAgg / Disp instances.
 
-  SGABlock.forward  models/GANet_deep.py:262-277   split + view + 4x normalize + SGA (+ bn_relu) -> GuidedSGABnRelu
+  SGABlock.forward  models/GANet_deep.py:262-277   split + view + 4x normalize + SGA (+ bn_relu) -> GuidedSGABnRelu;
+                                                   conv_refine's BatchNorm3d + `x += rem` + relu -> ResidualBnRelu (the convolution
+                                                   itself stays MIOpen's)
   DispAgg.forward   models/GANet_deep.py:239-247   after the upsampling: lga, Softmin, lga, normalize, regression -> DispAggTail
   Disp.forward      models/GANet_deep.py:213-219   after the upsampling: Softmin + regression -> SoftminDisparityRegression
   both tails        models/GANet_deep.py:212, 240  F.interpolate(trilinear) -> TrilinearUpsample (gather backward instead of
@@ -12,7 +14,7 @@ import types
 
 import torch
 
-from ganet_amd.modules.fused import (DispAggTail, GuidedSGA, GuidedSGABnRelu, SoftminDisparityRegression,
+from ganet_amd.modules.fused import (DispAggTail, GuidedSGA, GuidedSGABnRelu, ResidualBnRelu, SoftminDisparityRegression,
                                      TrilinearUpsample)
 
 _UP = TrilinearUpsample()
@@ -26,14 +28,11 @@ def _upsampled(self, x):
 
 def _sgablock_forward(self, x, g):
     rem = x
-    self._fused_sga.train(self.training)      # the helper is not a submodule: it follows the block's mode by hand
+    self._fused_sga.train(self.training)      # the helpers are not submodules: they follow the block's mode by hand
+    x = self._fused_sga(x, g)                 # normalise guidance + SGA (+ bn_relu)
     if self.refine:
-        x = self._fused_sga(x, g)             # normalise guidance + SGA + bn_relu
-        x = self.conv_refine(x)
-    else:
-        x = self.bn(self._fused_sga(x, g))
-    x += rem
-    return self.relu(x)
+        x = self.conv_refine.conv(x)          # BasicConv(relu=False) = Conv3d + BatchNorm3d (models/GANet_deep.py:238): the
+    return self._fused_tail(x, rem)           # BatchNorm, `x += rem` and the ReLU (:270-277) are ResidualBnRelu's one pass
 
 
 def _dispagg_forward(self, x, lg1, lg2):
@@ -54,6 +53,7 @@ def use_fused_ops(model):
             # keep the helper out of the module tree
             helper = GuidedSGABnRelu(m.bn_relu[0]) if m.refine else GuidedSGA()
             object.__setattr__(m, "_fused_sga", helper)
+            object.__setattr__(m, "_fused_tail", ResidualBnRelu(m.conv_refine.bn if m.refine else m.bn))
             m.forward = types.MethodType(_sgablock_forward, m)
             n += 1
         elif kind == "DispAgg":

@@ -35,7 +35,7 @@ extern "C" {
 #define GANET_E_UNSUPPORTED (-2)  /* shape outside the compiled kernel set         */
 #define GANET_E_RUNTIME (-3)      /* HIP runtime / launch error                    */
 
-#define GANET_ABI_VERSION 10      /* v10 = v8's entries (v9's ganet_lga2_filter_grad lost its A/B and is gone) */
+#define GANET_ABI_VERSION 11      /* v11 = v10 + ganet_residual_relu_forward / _backward (SGABlock's residual epilogue) */
 int ganet_abi_version(void);
 const char *ganet_last_error(void);
 /* 1 if this build runs the lockstep CPU emulator (tests only), 0 for the gfx950 build */
@@ -267,6 +267,20 @@ int ganet_trilinear_upsample_forward(const float *x, float *y, int S, int Di, in
                                      int Do, int Ho, int Wo, void *stream);
 int ganet_trilinear_upsample_backward(const float *grad_y, float *grad_x, int S, int Di, int Hi, int Wi,
                                       int Do, int Ho, int Wo, void *stream);
+
+/* The end of SGABlock.forward (models/GANet_deep.py:270-277): behind `conv_refine` (Conv3d + BatchNorm3d, no ReLU) the
+ * block adds its input back and applies ReLU,  `x += rem; return relu(x)`.  One pass:
+ *   y[n,c,d,h,w] = relu(bn_scale[c] * t + bn_shift[c] + rem)     t = the convolution's output, (bn_scale, bn_shift) = the
+ *                  BatchNorm3d folded from its running statistics (eval mode);
+ *   bn_scale == bn_shift == NULL:  y = relu(t + rem)             t = bn(conv(..)) as the framework computed it (training).
+ * y may alias t (the reference adds in place too).  relu as ATen's: [v <= 0] ? 0 : v (a NaN passes).
+ * Backward: g = [y <= 0] ? 0 : grad_y;  grad_rem = g;  grad_t = bn_scale[c] * g (bn_scale NULL: = g; grad_t NULL with
+ * bn_scale NULL: not written -- both inputs take grad_rem).
+ * Replaces: batch_norm (eval) + add_ + relu_ and their backward nodes -- 7 volume passes forward in stock PyTorch, 3 here. */
+int ganet_residual_relu_forward(const float *t, const float *rem, const float *bn_scale, const float *bn_shift,
+                                float *y, int N, int C, int D, int H, int W, void *stream);
+int ganet_residual_relu_backward(const float *y, const float *grad_y, const float *bn_scale, float *grad_t,
+                                 float *grad_rem, int N, int C, int D, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------- diagnostics ---- */
 

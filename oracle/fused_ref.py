@@ -6,6 +6,7 @@ sequence executed on the CPU (pinned by construction; torch CPU ships in this im
   lga_filters         models/GANet_deep.py:235       F.normalize(g, p=1, dim=1)
   norm_regression     models/GANet_deep.py:246-247 + libs/GANet/modules/GANet.py:142-147
                       F.normalize(x, p=1, dim=1), then sum(x * arange(maxdisp+1), 1)
+  sgablock_tail       models/GANet_deep.py:270-277   bn (of conv_refine) -> `x += rem` -> relu
   dispagg_tail        models/GANet_deep.py:243-247   lga -> Softmin(dim=1) -> lga -> normalize -> regression,
                       the two LGA2 calls through the C oracle (oracle/ganet_oracle.c)
 Gradients come from torch.autograd on the same CPU graph.
@@ -63,3 +64,12 @@ def dispagg_tail(x, lg1, lg2, maxdisp, ora, radius=2, parts=None):
     if parts is not None:
         parts["y2"] = x.detach()
     return norm_regression(x, maxdisp)
+
+
+def sgablock_tail(t, rem, bn):
+    """models/GANet_deep.py:270-277 behind the convolution: `x = bn(t)` (conv_refine's BatchNorm3d, BasicConv.forward :36-38;
+    refine=False blocks: the block's own bn, :273), `x += rem`, `relu(x)` -- the reference's statements on the CPU; `bn` is a
+    torch.nn.BatchNorm3d in whichever mode the caller put it."""
+    x = bn(t)
+    x += rem
+    return F.relu(x, inplace=True)

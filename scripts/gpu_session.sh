@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU session.  gpurun --timeout N -- 'bash scripts/gpu_session.sh <tag> [parts]'
-#   parts: any of  ubench tests smoke bench prof pmc modeltests model nofind  (default: tests smoke bench prof model)
+#   parts: any of  ubench tests smoke bench prof pmc modeltests model nofind census ab  (default: tests smoke bench prof model)
+#   census: the fused-vs-stock op censuses (scripts/bench_census*.py, bench_residual_tail.py);  ab: scripts/ab_step.py $AB_ARGS
 # Everything worth keeping goes to gpurun_out/<tag>/ (merged back into the dev container).
 TAG=${1:-r2}
 PARTS=${2:-"tests smoke bench prof model"}
@@ -54,6 +55,17 @@ if has pmc; then
   python scripts/pmc_summary.py $OUT/pmc > $OUT/pmc/summary.txt 2>&1
   python scripts/pmc_traffic.py $OUT/pmc/summary.txt $OUT/traffic_pmc.json > /dev/null 2>&1; echo "traffic rc=$?"
   find $OUT/pmc -name '*.csv' -size +2M -delete 2>/dev/null
+fi
+if has census; then
+  echo "== census (GA work of one inference pass / one training step, stock statements vs fused modules)"
+  timeout 300 python scripts/bench_residual_tail.py > $OUT/bench_residual_tail.json 2> $OUT/bench_residual_tail.err; echo "tail rc=$?"; cat $OUT/bench_residual_tail.json
+  timeout 300 python scripts/bench_census_infer.py --no-tail > $OUT/bench_census_infer_no_tail.json 2>> $OUT/census.err; echo "rc=$?"; cat $OUT/bench_census_infer_no_tail.json
+  timeout 300 python scripts/bench_census_infer.py > $OUT/bench_census_infer.json 2>> $OUT/census.err; echo "rc=$?"; cat $OUT/bench_census_infer.json
+  timeout 300 python scripts/bench_census.py > $OUT/bench_census.json 2>> $OUT/census.err; echo "rc=$?"; cat $OUT/bench_census.json
+fi
+if has ab; then
+  echo "== same-box whole-step A/B: ab_step.py $AB_ARGS"
+  timeout 900 python scripts/ab_step.py $AB_ARGS > $OUT/ab_step.txt 2> $OUT/ab_step.err; echo "ab rc=$?"; cat $OUT/ab_step.txt; tail -3 $OUT/ab_step.err
 fi
 if has modeltests; then
   echo "== model tests (reference models on the drop-in, GPU vs CPU-oracle twin)"

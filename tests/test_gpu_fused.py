@@ -223,3 +223,94 @@ def test_trilinear_upsample_vs_aten(torch_mod, ishape, osize):
         t_ours = timed(lambda: torch.autograd.grad(TrilinearUpsample()(x, osize), x, gy))
         t_aten = timed(lambda: torch.autograd.grad(F.interpolate(x2, size=list(osize), mode="trilinear", align_corners=False), x2, gy))
         print(f"trilinear upsample [1,1,65,80,208] -> [193,240,624] fwd+bwd: ours {t_ours:.3f} ms, ATen {t_aten:.3f} ms")
+
+
+def _bn3d(torch, C, seed):
+    bn = torch.nn.BatchNorm3d(C)
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5); bn.bias.copy_(torch.randn(C, generator=gen))
+        bn.running_mean.copy_(torch.randn(C, generator=gen)); bn.running_var.copy_(torch.rand(C, generator=gen) * 1.5 + 0.5)
+    return bn
+
+
+# the SGABlock volumes of cfg2 / cfg4 ([1,32,65,80,208], [1,48,33,40,104]), cfg3 ([1,32,65,128,416]) and cfg5 per GPU
+# ([2,32,65,176,320]); a slice size that is not a multiple of four (scalar kernel); an odd one
+_TAIL_SHAPES = [(1, 32, 65, 80, 208), (1, 48, 33, 40, 104), (1, 32, 65, 128, 416), (2, 32, 65, 176, 320), (2, 3, 5, 3, 7),
+                (1, 4, 9, 10, 12)]
+
+
+@pytest.mark.parametrize("shape", _TAIL_SHAPES)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_sgablock_residual_tail_matches_reference_statements(torch_mod, shape, mode):
+    """ResidualBnRelu(bn)(t, rem) == models/GANet_deep.py:270-277 behind the convolution (`x = bn(t); x += rem; relu(x)`,
+    oracle/fused_ref.sgablock_tail: the reference's statements on the CPU), forward and both gradients.
+    eval: the BatchNorm folded into one affine -- one rounding away from torch's (x - mean) * invstd * w + b: 1e-5 relative to
+    the pre-activation's size, and the gradients exact wherever the pre-activation is not within that rounding of zero.
+    train: bn runs in the framework (batch statistics), add + ReLU fused: <= 1e-5 against the CPU's own batch_norm."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import ResidualBnRelu
+    N, C = shape[:2]
+    torch.manual_seed(sum(shape))
+    t = torch.randn(shape, device="cuda", requires_grad=True)
+    rem = torch.randn(shape, device="cuda", requires_grad=True)
+    gy = torch.randn(shape, device="cuda")
+    bn = _bn3d(torch, C, 4).cuda().train(mode == "train")
+    if mode == "eval":
+        for p in bn.parameters():
+            p.requires_grad_(False)             # frozen statistics AND parameters: the folded one-pass form
+    y = ResidualBnRelu(bn, inplace=False)(t, rem)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    bn_cpu = _bn3d(torch, C, 4).train(mode == "train")
+    tc, rc = t.detach().cpu().requires_grad_(), rem.detach().cpu().requires_grad_()
+    want = fr.sgablock_tail(tc, rc, bn_cpu)
+    want.backward(gy.cpu())
+    wn = want.detach().numpy()
+    tol = 1e-5 * max(1.0, float(np.abs(wn).max()))
+    assert np.abs(_np(y) - wn).max() <= tol, np.abs(_np(y) - wn).max()
+    with torch.no_grad():
+        pre = (bn_cpu(tc.detach()) if mode == "eval" else None)
+    if mode == "eval":
+        clear = np.abs(pre.numpy() + rc.detach().numpy()) > tol
+        assert clear.mean() > 0.999
+        assert np.array_equal(_np(rem.grad)[clear], rc.grad.numpy()[clear])
+        np.testing.assert_allclose(_np(t.grad)[clear], tc.grad.numpy()[clear], rtol=1e-5, atol=1e-6)
+    else:
+        # the GPU's batch statistics differ from the CPU's in the last bits, so a handful of pre-activations change sign
+        bad = (_np(rem.grad) != rc.grad.numpy())
+        assert bad.mean() < 1e-4, bad.mean()
+        scale = max(1.0, float(tc.grad.abs().max()))
+        close = np.abs(_np(t.grad) - tc.grad.numpy()) <= 1e-4 * scale
+        assert close.mean() > 1 - 1e-4, close.mean()
+        # running statistics were updated by the framework exactly as without the fusion
+        np.testing.assert_allclose(_np(bn.running_mean), bn_cpu.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(_np(bn.running_var), bn_cpu.running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_sgablock_residual_tail_in_place_and_no_grad(torch_mod):
+    """in place over t (what the harness uses: t is the convolution's output) == out of place; under no_grad nothing is kept;
+    an in-place call on a non-leaf with autograd on differentiates through the producer of t."""
+    torch = torch_mod
+    from ganet_amd.modules.fused import ResidualBnRelu
+    torch.manual_seed(8)
+    shape = (1, 4, 9, 10, 12)
+    bn = _bn3d(torch, 4, 5).cuda().eval()
+    for p in bn.parameters():
+        p.requires_grad_(False)
+    t, rem = torch.randn(shape, device="cuda"), torch.randn(shape, device="cuda")
+    with torch.no_grad():
+        want = torch.relu(bn(t) + rem)
+        t2 = t.clone()
+        got = ResidualBnRelu(bn)(t2, rem)
+        assert got.data_ptr() == t2.data_ptr()
+    assert float((got - want).abs().max()) <= 1e-5
+    w = torch.randn(shape, device="cuda", requires_grad=True)
+    rem.requires_grad_()
+    y = ResidualBnRelu(bn)(w * 2.0, rem)                      # t = a temporary with a producer
+    y.sum().backward()
+    w2, rem2 = w.detach().clone().requires_grad_(), rem.detach().clone().requires_grad_()
+    torch.relu(bn(w2 * 2.0) + rem2).sum().backward()
+    assert float((w.grad - w2.grad).abs().max()) <= 1e-5 and float((rem.grad - rem2.grad).abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ResidualBnRelu(bn)(t.cpu(), rem.detach().cpu())        # no CPU path

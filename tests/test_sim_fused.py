@@ -232,3 +232,87 @@ def test_lga_pass_with_regression_epilogue(sim, port_oracle, shape, r, with_y):
     d = np.arange(D, dtype=np.float64)[None, :, None, None]
     np.testing.assert_allclose(snorm, np.abs(want.astype(np.float64)).sum(1), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(sdy, (want.astype(np.float64) * d).sum(1), rtol=1e-5, atol=2e-4)
+
+
+def _bn3d(C, seed, affine=True):
+    """a BatchNorm3d with non-trivial statistics and affine parameters"""
+    bn = torch.nn.BatchNorm3d(C, affine=affine)
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(C, generator=gen))
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.25)
+        if affine:
+            bn.weight.copy_(torch.randn(C, generator=gen))
+            bn.bias.copy_(torch.randn(C, generator=gen))
+    return bn
+
+
+def _folded(bn):
+    scale = (bn.running_var + bn.eps).rsqrt() * (bn.weight if bn.affine else 1.0)
+    shift = (bn.bias if bn.affine else 0.0) - bn.running_mean * scale
+    return (np.ascontiguousarray(scale.detach().numpy().astype(np.float32)),
+            np.ascontiguousarray(shift.detach().numpy().astype(np.float32)))
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 3, 4, 8), (2, 3, 5, 3, 7), (2, 1, 1, 1, 1), (1, 5, 2, 2, 6)])
+@pytest.mark.parametrize("folded", [True, False])
+def test_sgablock_residual_tail(sim, shape, folded):
+    """ganet_residual_relu_forward / _backward == models/GANet_deep.py:270-277 behind the convolution (bn -> `x += rem` -> relu):
+    eval mode with the BatchNorm folded into (scale, shift), and the training form relu(u + rem) on u = bn(t) from torch;
+    16-byte and scalar kernels (slice sizes 96 / 105 / 1 / 24), out of place and in place."""
+    N, C, D, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    t = rng.standard_normal(shape).astype(np.float32)
+    rem = rng.standard_normal(shape).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    bn = _bn3d(C, 11).eval() if folded else _bn3d(C, 11).train()
+    tt, tr = torch.from_numpy(t.copy()).requires_grad_(), torch.from_numpy(rem.copy()).requires_grad_()
+    want = fr.sgablock_tail(tt, tr, bn)
+    want.backward(torch.from_numpy(gy))
+    if folded:
+        scale, shift = _folded(bn)
+        src, ps, ph = t, _p(scale), _p(shift)
+    else:
+        with torch.no_grad():
+            src = np.ascontiguousarray(_bn3d(C, 11).train()(torch.from_numpy(t)).numpy())      # u = bn(t): the framework's part
+        ps = ph = None
+    y = np.full(shape, np.nan, np.float32)
+    _call(sim, "ganet_residual_relu_forward", _p(src), _p(rem), ps, ph, _p(y), N, C, D, H, W, None)
+    np.testing.assert_allclose(y, want.detach().numpy(), rtol=1e-5, atol=1e-6)
+    # relu's zero set is exactly the reference's wherever the pre-activation is not within rounding of zero
+    pre = (bn.eval() if folded else bn)(torch.from_numpy(t)).detach().numpy() + rem if folded else src + rem
+    clear = np.abs(pre) > 1e-5
+    assert np.array_equal((y > 0)[clear], (want.detach().numpy() > 0)[clear])
+    # in place over t
+    y2 = src.copy()
+    api_y2 = pc.guarded_empty(shape, np.float32, _GUARD)
+    api_y2[...] = y2
+    sim.call("ganet_residual_relu_forward", api_y2.ctypes.data, np.ascontiguousarray(rem).ctypes.data,
+             ps.a.ctypes.data if ps else None, ph.a.ctypes.data if ph else None, api_y2.ctypes.data, N, C, D, H, W, None)
+    assert np.array_equal(api_y2, y)
+    # backward
+    g_rem = np.full(shape, np.nan, np.float32)
+    if folded:
+        g_t = np.full(shape, np.nan, np.float32)
+        _call(sim, "ganet_residual_relu_backward", _p(y), _p(gy), ps, _p(g_t), _p(g_rem), N, C, D, H, W, None)
+        np.testing.assert_allclose(g_t[clear], tt.grad.numpy()[clear], rtol=1e-5, atol=1e-6)
+    else:
+        _call(sim, "ganet_residual_relu_backward", _p(y), _p(gy), None, None, _p(g_rem), N, C, D, H, W, None)
+    assert np.array_equal(g_rem[clear], tr.grad.numpy()[clear])          # a masked copy: exact
+
+
+def test_sgablock_residual_tail_argument_checks(sim):
+    from ganet_amd import _native
+    a = np.zeros((1, 2, 2, 2, 4), np.float32)
+    sc = np.ones(2, np.float32)
+    with pytest.raises(_native.GanetError):        # scale without shift
+        sim.call("ganet_residual_relu_forward", a.ctypes.data, a.ctypes.data, sc.ctypes.data, None, a.ctypes.data, 1, 2, 2, 2, 4, None)
+    with pytest.raises(_native.GanetError):        # a scaled gradient needs grad_t
+        sim.call("ganet_residual_relu_backward", a.ctypes.data, a.ctypes.data, sc.ctypes.data, None, a.ctypes.data, 1, 2, 2, 2, 4, None)
+    with pytest.raises(_native.GanetError):
+        sim.call("ganet_residual_relu_forward", a.ctypes.data, a.ctypes.data, None, None, a.ctypes.data, 1, 0, 2, 2, 4, None)
+    # NaN passes through relu as in ATen
+    t = np.array([np.nan, -1.0, 2.0, 0.0], np.float32).reshape(1, 1, 1, 1, 4)
+    y = np.empty_like(t)
+    sim.call("ganet_residual_relu_forward", t.ctypes.data, np.zeros_like(t).ctypes.data, None, None, y.ctypes.data, 1, 1, 1, 1, 4, None)
+    assert np.isnan(y.ravel()[0]) and list(y.ravel()[1:]) == [0.0, 2.0, 0.0]
