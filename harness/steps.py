@@ -65,23 +65,37 @@ def train_step(model, optimizer, name, left, right, target, max_disp, crit):
     # returned early would leave the others waiting in the gradient all-reduce.  The step is skipped only if no
     # rank has a valid pixel; a rank whose own shard is empty runs forward + backward with a zero-weighted loss.
     nvalid = mask.sum()
-    total = nvalid.clone()
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        torch.distributed.all_reduce(total)
-    if int(total) == 0:
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    stat = torch.stack([nvalid, (nvalid == 0).to(nvalid.dtype)])       # valid pixels of all ranks, ranks with an empty shard
+    if multi:
+        torch.distributed.all_reduce(stat)
+    total, n_empty = int(stat[0]), int(stat[1])
+    if total == 0:
         return None, None
     optimizer.zero_grad()
     outputs = model(left, right)
     if int(nvalid) == 0:
-        # A zero loss that reaches every parameter WITHOUT going through the data path: the forward above ran (its collectives --
-        # SyncBN statistics -- stay aligned with the other ranks), but a non-finite activation anywhere in it would turn
-        # 0 * output into NaN weight gradients and poison the all-reduce of the ranks that do have valid pixels.
-        loss = sum(p.sum() for p in model.parameters() if p.requires_grad) * 0.0
+        # EVERY rank runs the same backward graph: DDP's reducer marks unused parameters ready on its own (a loss that
+        # touched them directly made it mark them twice), and SyncBatchNorm's backward all-reduces on the default group -- a rank
+        # that bypassed the data path would issue a different collective sequence than its peers.  So the zero-weighted loss
+        # stays ON the forward graph; what that can do to the gradients (0 * inf = NaN) is dealt with after the backward.
+        loss = sum(torch.nan_to_num(o).sum() for o in outputs) * 0.0
         err = loss.detach()
     else:
         loss = loss_mix(name, outputs, target, mask, crit)
         err = torch.mean(torch.abs(outputs[-1][mask] - target[mask])).detach()
     loss.backward()
+    if multi and n_empty:
+        # a non-finite activation on a zero-weighted rank has reached everybody's averaged gradients by now: the step is skipped
+        # by a COLLECTIVE decision (the averaged gradients are the same on every rank; the flag is reduced all the same, so that
+        # no rank can step alone)
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        bad = (~torch.isfinite(torch.stack(torch._foreach_norm(grads)))).any().to(torch.int32) if grads else torch.zeros((), dtype=torch.int32)
+        bad = bad.to(nvalid.device)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if int(bad):
+            optimizer.zero_grad()
+            return loss.detach(), err
     optimizer.step()
     return loss.detach(), err
 

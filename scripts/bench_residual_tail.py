@@ -12,12 +12,24 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
 
-def timed(fn, iters=10):
-    fn(); fn(); torch.cuda.synchronize()
+def timed(fn, iters=20):
+    """device time of fn: captured once into a hipGraph and replayed (these tails are 20 - 500 us of kernels: an eager loop
+    measures the host -- a Python autograd.Function + ctypes call against three ATen dispatches -- not the GPU, which is what
+    bounds a model pass whose host runs far ahead of 60 - 500 ms of convolutions)"""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn(); fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        fn()
+        g.replay()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / iters
 

@@ -143,12 +143,16 @@ def _skip_worker(rank, world, port, q):
         def __init__(self):
             super().__init__()
             self.c = torch.nn.Conv2d(6, 2, 3, padding=1)
+            self.never_called = torch.nn.Linear(3, 3)    # like GANet_deep's cost_agg.deconv0b (constructed, never used)
+            self.blow = 0.0
 
         def forward(self, left, right):
             o = self.c(torch.cat([left, right], 1))
+            o = o + self.blow * o                        # blow = inf: a non-finite activation on this rank
             return o[:, 0], o[:, 1]
     torch.manual_seed(0)
-    model = DDP(Toy())
+    model = DDP(Toy(), find_unused_parameters=True)      # what harness/train.py sets for GANet_deep (the empty-shard
+    # loss used to touch the unused parameters directly -> "Expected to mark a variable ready only once" on the empty rank)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     max_disp = 24
     left, right, target = steps.synthetic_batch(1, 8, 12, max_disp, "cpu", seed=rank)
@@ -160,6 +164,13 @@ def _skip_worker(rank, world, port, q):
     # step 2: no rank has a valid pixel: both skip
     out.append(steps.train_step(model, opt, "GANet11", left, right, torch.full_like(target, float(max_disp)), max_disp, crit)[0] is None)
     digest = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    # step 3: the zero-weighted rank's forward overflows: 0 * inf would put NaN into everybody's averaged gradients -- the step
+    # is skipped collectively, parameters stay as they were (and finite) on both ranks
+    if rank == 1:
+        model.module.blow = float("inf")
+    out.append(steps.train_step(model, opt, "GANet11", left, right, t1, max_disp, crit)[0] is not None)
+    after = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+    out.append(after == digest and bool(all(torch.isfinite(p).all() for p in model.parameters())))
     q.put((rank, out, digest))
     dist.destroy_process_group()
 
@@ -178,5 +189,5 @@ def test_batch_without_valid_pixels_is_skipped_collectively():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0][1] == [True, True] and res[1][1] == [True, True]
+    assert res[0][1] == [True, True, True, True] and res[1][1] == [True, True, True, True]
     assert res[0][2] == res[1][2], "identical parameters after the shared step"
