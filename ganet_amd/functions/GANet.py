@@ -313,54 +313,64 @@ class DisparityRegressionFunction(Function):
         return gx, None
 
 
+def _piecewise(v, *stages):
+    """v pushed through pure piecewise maps one after the other: stage = (condition(v), replacement(v)) -> where(cond, repl, v).
+    The reference writes its robust losses as masked updates of ONE buffer, so a value moved by an earlier update is seen by
+    the later conditions; a chain of maps says the same thing without touching a buffer in place."""
+    for cond, repl in stages:
+        v = torch.where(cond(v), repl(v), v)
+    return v
+
+
 class MyLoss2Function(Function):
-    """Robust loss of functions/GANet.py:264-289 (pure tensor ops; kept for API parity)."""
+    """MyLoss2Function.apply(input1, input2, thresh=1, alpha=2): mean of rho(|input1 - input2|), rho quadratic below `thresh`,
+    a concave parabola on [thresh, thresh + alpha], linear (+ alpha / 2) beyond; its backward is the reference's own slope
+    table, not d rho (functions/GANet.py:264-289; pure tensor ops, kept for API parity)."""
 
     @staticmethod
     def forward(ctx, input1, input2, thresh=1, alpha=2):
-        ctx.thresh, ctx.alpha = thresh, alpha
-        diff = input1 - input2
-        temp = torch.abs(diff)
-        lo = temp < thresh
-        temp[lo] = temp[lo] ** 2 / thresh
-        tag = (temp <= thresh + alpha) & (temp >= thresh)
-        temp[tag] = temp[tag] * 2 - (temp[tag] - thresh) ** 2 / (2.0 * alpha) - thresh
-        temp[temp > thresh + alpha] += alpha / 2.0
-        ctx.save_for_backward(diff)
-        return torch.mean(temp)
+        ctx.knee, ctx.span = thresh, alpha
+        residual = input1 - input2
+        ctx.save_for_backward(residual)
+        knee, far = thresh, thresh + alpha
+        rho = _piecewise(residual.abs(),
+                         (lambda v: v < knee, lambda v: v * v / knee),
+                         (lambda v: (v >= knee) & (v <= far), lambda v: 2 * v - (v - knee) ** 2 / (2.0 * alpha) - knee),
+                         (lambda v: v > far, lambda v: v + alpha / 2.0))
+        return rho.mean()
 
     @staticmethod
-    def backward(ctx, gradOutput):
-        diff, = ctx.saved_tensors
-        scale = torch.abs(diff)
-        scale[scale > ctx.thresh + ctx.alpha] = 1
-        tag = (scale <= ctx.thresh + ctx.alpha) & (scale >= ctx.thresh)
-        scale[tag] = 2 - (scale[tag] - ctx.thresh) / ctx.alpha
-        tag = scale < ctx.thresh
-        scale[tag] = 2 * scale[tag] / ctx.thresh
-        sign = torch.sign(diff)
-        grad = sign * scale * gradOutput / scale.numel()
+    def backward(ctx, grad_loss):
+        residual, = ctx.saved_tensors
+        knee, far = ctx.knee, ctx.knee + ctx.span
+        slope = _piecewise(residual.abs(),
+                           (lambda v: v > far, torch.ones_like),
+                           (lambda v: (v >= knee) & (v <= far), lambda v: 2 - (v - knee) / ctx.span),
+                           (lambda v: v < knee, lambda v: 2 * v / knee))
+        grad = torch.sign(residual) * slope * grad_loss / residual.numel()
         # the reference hands back a one-element zero tensor for input2 (functions/GANet.py:289): the target never
         # receives a gradient; here: zeros of the right shape when autograd asks for one, else None
-        return grad, (torch.zeros_like(diff) if ctx.needs_input_grad[1] else None), None, None
+        return grad, (torch.zeros_like(residual) if ctx.needs_input_grad[1] else None), None, None
 
 
 class MyLossFunction(Function):
-    """functions/GANet.py:291-310."""
+    """MyLossFunction.apply(input1, input2, upper_thresh=5, lower_thresh=1): mean |input1 - input2| with the reference's
+    re-weighted gradient -- slope 2 at the middle of [lower, upper] falling to 1 at a distance of 2, slope 1 above `upper`,
+    |residual| itself below `lower`; not divided by the element count (functions/GANet.py:291-310)."""
 
     @staticmethod
     def forward(ctx, input1, input2, upper_thresh=5, lower_thresh=1):
-        ctx.upper_thresh, ctx.lower_thresh = upper_thresh, lower_thresh
-        diff = input1 - input2
-        ctx.save_for_backward(diff)
-        return torch.mean(torch.abs(diff))
+        ctx.band = (lower_thresh, upper_thresh)
+        residual = input1 - input2
+        ctx.save_for_backward(residual)
+        return residual.abs().mean()
 
     @staticmethod
-    def backward(ctx, gradOutput):
-        diff, = ctx.saved_tensors
-        scale = torch.abs(diff)
-        scale[scale > ctx.upper_thresh] = 1
-        tag = (scale <= ctx.upper_thresh) & (scale >= ctx.lower_thresh)
-        scale[tag] = 2 - torch.abs(scale[tag] - (ctx.upper_thresh + ctx.lower_thresh) / 2.) / 2.
-        grad = torch.sign(diff) * scale * gradOutput
-        return grad, (torch.zeros_like(diff) if ctx.needs_input_grad[1] else None), None, None   # functions/GANet.py:310
+    def backward(ctx, grad_loss):
+        residual, = ctx.saved_tensors
+        lo, hi = ctx.band
+        slope = _piecewise(residual.abs(),
+                           (lambda v: v > hi, torch.ones_like),
+                           (lambda v: (v >= lo) & (v <= hi), lambda v: 2 - (v - (hi + lo) / 2.).abs() / 2.))
+        grad = torch.sign(residual) * slope * grad_loss
+        return grad, (torch.zeros_like(residual) if ctx.needs_input_grad[1] else None), None, None   # functions/GANet.py:310

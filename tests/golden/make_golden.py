@@ -1,7 +1,9 @@
 """Generates the committed golden vectors from the REFERENCE's own kernel bodies.
 
 Run in the dev container only (needs /root/reference to build oracle/_ref):
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py              the small fixtures (tests/golden/*.npz)
+    python tests/golden/make_golden.py --digests    sha256 of every output of the reference at the FULL model shapes
+                                                    (BASELINE configs[1] and the SGA-B / cfg3 volumes) -> tests/golden/digests.json
 Every output array below comes from oracle/_ref/libganet_ref.so, i.e. from
 /root/reference/libs/GANet/src/GANet_kernel.cu compiled through oracle/ref_shim
 with the launch order of its host launchers (GANet_kernel.cu:935-1129, 1271-1364)
@@ -99,5 +101,27 @@ def main():
         print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
 
 
+# ---- full-size digests (cases, inputs and the digest walk: tests/golden_util.py, shared with the tests that hold the C
+# restatement and the GPU to them) ----------------------------------------------------------------------------------
+sys.path.insert(0, os.path.dirname(HERE))
+import golden_util as gu  # noqa: E402
+
+
+def digests():
+    import json
+    ref = Oracle("reference")
+    out = {"_made_by": "tests/golden/make_golden.py --digests: sha256 of the float32 / uint8 bytes of each array computed by "
+                       "oracle/_ref (the reference's own kernel bodies, GANet_kernel.cu:23-1269, launch order :935-1129, 1271-1322)"}
+    for name, shape, seed in gu.SGA_DIGEST_CASES:
+        out[name] = {"shape": list(shape), "seed": seed, "sha256": gu.sga_digests(ref, shape, seed)}
+        print(name, "done")
+    for name, shape, seed in gu.LGA_DIGEST_CASES:
+        out[name] = {"shape": list(shape), "seed": seed, "sha256": gu.lga_digests(ref, shape, seed)}
+        print(name, "done")
+    with open(os.path.join(HERE, "digests.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+        fh.write("\n")
+
+
 if __name__ == "__main__":
-    main()
+    digests() if "--digests" in sys.argv else main()

@@ -29,3 +29,75 @@ def assert_bit_equal(a, b, what=""):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     bad = bits(a) != bits(b)
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} words differ, max abs {np.abs(a - b).max()}"
+
+
+# ---- full-size digests (tests/golden/digests.json, made by tests/golden/make_golden.py --digests from oracle/_ref) -------------
+def _l1norm(g, axis):
+    return (g / np.abs(g).sum(axis, keepdims=True)).astype(np.float32)
+
+
+def load_digests():
+    import json
+    with open(os.path.join(GOLDEN, "digests.json")) as fh:
+        return json.load(fh)
+
+
+# The inputs are the seeded ones of tests/test_gpu_parity.py (test_full_size_cfg2_against_oracle, test_sga_model_shapes_vs_oracle,
+# test_lga_model_shapes_vs_oracle): numpy's default_rng (PCG64) is a documented stable stream, and the digests of the INPUTS are
+# stored too, so a change of the generator would be noticed as such.
+SGA_DIGEST_CASES = [  # (name, shape, seed)
+    ("sga_cfg2", (1, 32, 65, 80, 208), 123),                       # BASELINE configs[1]
+    ("sga_b", (1, 48, 33, 40, 104), 1 + 48 + 33 + 40 + 104),        # the 1/6-resolution volumes of cfg2 / cfg4
+    ("sga_cfg3", (1, 32, 65, 128, 416), 1 + 32 + 65 + 128 + 416),   # KITTI 1248x384
+]
+LGA_DIGEST_CASES = [  # (name, shape, seed): Lga2Function, radius 2
+    ("lga2_cfg2", (1, 193, 240, 624), 123),
+    ("lga2_cfg3", (1, 193, 384, 1248), 1 + 193 + 384 + 1248),
+]
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sga_digest_inputs(shape, seed):
+    """= tests/parity_cases.sga_inputs"""
+    rng = np.random.default_rng(seed)
+    N, C, D, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    gs = [_l1norm(rng.standard_normal((N, C, 5, H, W)), 2) for _ in range(4)]
+    go = rng.standard_normal(shape).astype(np.float32)
+    return x, gs, go
+
+
+def lga_digest_inputs(shape, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape).astype(np.float32)
+    f = _l1norm(rng.standard_normal((shape[0], 75) + tuple(shape[2:])), 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    return x, f, gy
+
+
+def sga_digests(ora, shape, seed):
+    """every array SgaFunction produces, forward and backward, as the oracle `ora` computes it -> {name: sha256}"""
+    x, gs, go = sga_digest_inputs(shape, seed)
+    d = {"in.x": sha(x), "in.go": sha(go), **{f"in.g{k}": sha(gs[k]) for k in range(4)}}
+    out, tmp, mask = ora.sga_forward(x, *gs)
+    d.update({"out": sha(out), "temp_out": sha(tmp), "mask_u8": sha(mask.astype(np.uint8))})
+    for k in range(4):
+        d[f"A{k}"] = sha(ora.sga_scan(x, gs[k], k))
+    for n, g in zip(("gx", "gw0", "gw1", "gw2", "gw3"), ora.sga_backward(x, *gs, tmp, mask, go)):
+        d[n] = sha(g)
+    return d
+
+
+def lga_digests(ora, shape, seed):
+    x, f, gy = lga_digest_inputs(shape, seed)
+    d = {"in.x": sha(x), "in.f": sha(f), "in.gy": sha(gy)}
+    y, ins = ora.lga_chain_forward(x, f, 2, 2)
+    gx, gf = ora.lga_chain_backward(ins, f, gy, 2)
+    d.update({"t1": sha(ins[1]), "y": sha(y), "gx": sha(gx), "gf": sha(gf)})
+    return d
+
+

@@ -173,6 +173,24 @@ def test_full_size_cfg2_against_oracle(api, dev, port_oracle):
     print("cfg2 LGA2 max-abs errors:", err)
 
 
+@pytest.mark.parametrize("name", ["sga_cfg2", "sga_b", "sga_cfg3"])
+def test_sga_full_size_forward_matches_reference_digests(api, dev, name):
+    """The bit-exact outputs of SGA's forward at the full model shapes -- out, the direction mask, the four directional volumes,
+    A_left under the reference's name temp_out -- hashed on the host and compared with the sha256 the REFERENCE's own kernel bodies
+    produced on the same seeded inputs (tests/golden/digests.json, made here from oracle/_ref by make_golden.py --digests).  The
+    GPU box has no /root/reference: this is its direct link to the reference at BASELINE configs[1]'s size, past the restatement."""
+    import golden_util as gu
+    want = gu.load_digests()[name]
+    shape, seed = tuple(want["shape"]), want["seed"]
+    x, gs, _ = gu.sga_digest_inputs(shape, seed)
+    assert gu.sha(x) == want["sha256"]["in.x"] and all(gu.sha(gs[k]) == want["sha256"][f"in.g{k}"] for k in range(4))
+    _, _, A, out, mask, _ = pc.run_sga_forward(api, dev, x, gs)
+    hA = dev.host(A)
+    got = {"out": gu.sha(dev.host(out)), "mask_u8": gu.sha(dev.host(mask)), "temp_out": gu.sha(hA[3]),
+           **{f"A{k}": gu.sha(hA[k]) for k in range(4)}}
+    assert got == {k: want["sha256"][k] for k in got}, [k for k in got if got[k] != want["sha256"][k]]
+
+
 @pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 32, 65, 80, 208), (1, 4, 33, 8, 48), (2, 3, 48, 12, 80), (1, 2, 9, 4, 16)])
 def test_sga_tiled_private_workspace(api, dev, port_oracle, shape, tiled):

@@ -73,3 +73,28 @@ def test_cost_volume_and_regression_match_torch_restatement(port_oracle):
     disp = torch.arange(maxdisp + 1, dtype=torch.float32).view(1, -1, 1, 1)
     ref = torch.sum(p * disp, 1).numpy()
     np.testing.assert_allclose(port_oracle.disparity_regression(p.numpy(), maxdisp), ref, atol=1e-6)
+
+
+# ---- the FULL model shapes, by digest (tests/golden/digests.json <- make_golden.py --digests <- oracle/_ref) ----------------
+import golden_util as gu  # noqa: E402
+
+
+@pytest.mark.parametrize("name,shape,seed", gu.SGA_DIGEST_CASES)
+def test_sga_full_size_restatement_matches_reference_digests(port_oracle, name, shape, seed):
+    """BASELINE configs[1]'s SGA volume [1,32,65,80,208], the 1/6-resolution volume and cfg3's: every array of SgaFunction's
+    forward and backward as the C restatement computes it has the sha256 the REFERENCE's kernel bodies gave on the same seeded
+    inputs -- the full-shape link between restatement and reference that does not need /root/reference at test time."""
+    want = gu.load_digests()[name]
+    assert tuple(want["shape"]) == shape and want["seed"] == seed
+    got = gu.sga_digests(port_oracle, shape, seed)
+    assert {k: v for k, v in got.items() if k.startswith("in.")} == {k: v for k, v in want["sha256"].items() if k.startswith("in.")}, \
+        "the seeded inputs themselves differ (numpy's generator?)"
+    assert got == want["sha256"], [k for k in got if got[k] != want["sha256"][k]]
+
+
+@pytest.mark.parametrize("name,shape,seed", gu.LGA_DIGEST_CASES)
+def test_lga2_full_size_restatement_matches_reference_digests(port_oracle, name, shape, seed):
+    """Lga2Function (radius 2) at [1,193,240,624] (configs[1]) and [1,193,384,1248] (cfg3): intermediate, output and both gradients."""
+    want = gu.load_digests()[name]
+    got = gu.lga_digests(port_oracle, shape, seed)
+    assert got == want["sha256"], [k for k in got if got[k] != want["sha256"][k]]
