@@ -37,24 +37,35 @@ def build_hip(force=False, extra_flags=(), out=OUT, verbose=False):
         if os.path.exists(out):
             return out      # GPU box without a toolchain: use the prebuilt library as shipped
         raise RuntimeError("hipcc not found and no prebuilt libganet_hip.so")
-    objs, procs = [], []
-    for src, extra in SOURCES.items():
-        obj = os.path.join(_HERE, "csrc", f"{src}.{os.getpid()}.o")      # (two processes building at once must not share object files)
-        cmd = [hipcc] + HIPCC_FLAGS + extra + list(extra_flags) + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + LIB_SONAME] + objs + ["-o", f"{out}.{os.getpid()}.tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    for o in objs:
-        os.remove(o)
-    os.replace(f"{out}.{os.getpid()}.tmp", out)
+    # Objects and the not-yet-complete library live in a directory of this build's own (two processes building at once share
+    # nothing); whatever happens -- a failed or interrupted compile included -- the directory goes and the other compiles are
+    # stopped (per-PID objects used to stay behind in csrc/ after a failure).
+    import tempfile
+    procs = []
+    with tempfile.TemporaryDirectory(prefix="ganet_build_", dir=os.path.dirname(os.path.abspath(out))) as tmp:
+        try:
+            objs = []
+            for src, extra in SOURCES.items():
+                obj = os.path.join(tmp, src + ".o")
+                cmd = [hipcc] + HIPCC_FLAGS + extra + list(extra_flags) + ["-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((cmd, subprocess.Popen(cmd)))
+                objs.append(obj)
+            for cmd, pr in procs:
+                if pr.wait() != 0:
+                    raise subprocess.CalledProcessError(pr.returncode, cmd)
+            lib_tmp = os.path.join(tmp, os.path.basename(out))
+            cmd = [hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-Wl,-soname," + LIB_SONAME] + objs + ["-o", lib_tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(lib_tmp, out)          # same directory tree as `out`: an atomic rename
+        finally:
+            for _, pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                    pr.wait()
     return out
 
 

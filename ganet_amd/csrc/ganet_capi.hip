@@ -75,20 +75,30 @@ struct Options {
 Options g_opt;
 std::once_flag g_opt_once;
 
+// the one place an option value is normalised: ganet_set_option and the environment go through it (GANET_LGA_WAVE=-1
+// from the environment used to be stored as is, truthy, and reported as -1)
+bool store_option(const char *name, int value)
+{
+  auto tri = [](int v) { return v < 0 ? 0 : (v > 2 ? 2 : v); };
+  if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = tri(value);
+  else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
+  else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
+  else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = tri(value);
+  else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = tri(value);
+  else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
+  else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
+  else return false;
+  return true;
+}
+
 void load_env_options()
 {
-  auto geti = [](const char *name, std::atomic<int> &dst) {
+  for (const char *name : {"GANET_LGA_WAVE", "GANET_SGA_TILED", "GANET_LGA_SEGS", "GANET_LGA_MIX", "GANET_SGA_WIDE_SCAN",
+                           "GANET_SGA_WIDE_COL", "GANET_SGA_ROWWAVE", "GANET_SGA_COLBLOCK"}) {
     const char *v = getenv(name);
-    if (v && *v) dst = atoi(v);
-  };
-  geti("GANET_LGA_WAVE", g_opt.lga_wave);
-  geti("GANET_SGA_TILED", g_opt.sga_tiled);
-  geti("GANET_LGA_SEGS", g_opt.lga_segs);
-  geti("GANET_LGA_MIX", g_opt.lga_mix);
-  geti("GANET_SGA_WIDE_SCAN", g_opt.wide_scan);
-  geti("GANET_SGA_WIDE_COL", g_opt.wide_col);
-  geti("GANET_SGA_ROWWAVE", g_opt.rowwave);
-  geti("GANET_SGA_COLBLOCK", g_opt.colblock);
+    if (v && *v) store_option(name, atoi(v));
+  }
 }
 const Options &opts()
 {
@@ -789,14 +799,7 @@ GA_EXPORT int ganet_set_option(const char *name, int value)
 {
   opts();
   if (!name) return fail(GANET_E_INVALID, "ganet_set_option: null name");
-  if (!strcmp(name, "GANET_LGA_WAVE")) g_opt.lga_wave = value < 0 ? 0 : value > 2 ? 2 : value;
-  else if (!strcmp(name, "GANET_SGA_TILED")) g_opt.sga_tiled = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_LGA_MIX")) g_opt.lga_mix = value < 0 ? 0 : value;      // 1: S = SIMDs of the device; n > 1: S = n (tests)
-  else if (!strcmp(name, "GANET_LGA_SEGS")) g_opt.lga_segs = value > 0 ? value : 0;
-  else if (!strcmp(name, "GANET_SGA_WIDE_SCAN")) g_opt.wide_scan = value < 0 ? 0 : (value > 2 ? 2 : value);
-  else if (!strcmp(name, "GANET_SGA_WIDE_COL")) g_opt.wide_col = value < 0 ? 0 : (value > 2 ? 2 : value);
-  else if (!strcmp(name, "GANET_SGA_ROWWAVE")) g_opt.rowwave = value ? 1 : 0;
-  else if (!strcmp(name, "GANET_SGA_COLBLOCK")) g_opt.colblock = value ? 1 : 0;
+  if (store_option(name, value)) {}      // a library option, normalised
 #if defined(GA_HIPSIM)
   else if (!strcmp(name, "HIPSIM_LATE_DMA")) hipsim::S().late_dma = value != 0;   // emulator only: see tests/hipsim/hipsim.h
   else if (!strcmp(name, "HIPSIM_LANE_ORDER")) hipsim::S().lane_order = value ? 1 : 0;

@@ -183,6 +183,17 @@ def test_option_table(built_lib):
             lib.ganet_set_option(n, v)
 
 
+def test_options_from_the_environment_are_normalised_like_set_option(built_lib):
+    """GANET_LGA_WAVE=-1 in the environment used to be stored unclamped (truthy, reported as -1)."""
+    import subprocess
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); lib.ganet_get_option.argtypes = [ctypes.c_char_p]; "
+            "print(*[lib.ganet_get_option(n) for n in (b'GANET_LGA_WAVE', b'GANET_SGA_WIDE_COL', b'GANET_SGA_TILED', b'GANET_LGA_SEGS')])")
+    for env, want in (({"GANET_LGA_WAVE": "-1", "GANET_SGA_WIDE_COL": "9", "GANET_SGA_TILED": "5", "GANET_LGA_SEGS": "-4"}, "0 2 1 0"),
+                      ({"GANET_LGA_WAVE": "1", "GANET_SGA_WIDE_COL": "0", "GANET_SGA_TILED": "0", "GANET_LGA_SEGS": "3"}, "1 0 0 3")):
+        out = subprocess.run([sys.executable, "-c", code, built_lib], env={**os.environ, **env}, capture_output=True, text=True, check=True)
+        assert out.stdout.split() == want.split(), (env, out.stdout)
+
+
 def test_traffic_file_names_the_tree_it_was_measured_on():
     """profiles/traffic_pmc.json carries the hash of ganet_amd/csrc/ it was measured on (scripts/pmc_traffic.py) and bench.py
     compares it with this tree's: the committed file must describe the committed kernels, and the hash must
