@@ -127,13 +127,17 @@ def test_reference_models_import_on_top_of_the_drop_in(monkeypatch):
 
 def test_bench_roofline_object_from_stage_times():
     """bench.roofline_from_stages on the stage names bench.stage_timings produces (no GPU): every family row is built from the
-    kernels' own times (no difference of other measurements), LGA families carry the fp32 bound, the line states the MFMA answer
-    and the measured-achievable peaks, and the per-kernel traffic lookup accepts the alternative names of one kernel."""
+    kernels' own times (no difference of other measurements), LGA families carry the fp32 bound, the HEADLINE object is one kernel
+    under its rocprof name (the launch with the largest share of the step: VERDICT r5 item 5) with the dominant and the worst
+    family named beside it, the line states the MFMA answer and the measured-achievable peaks, and the per-kernel traffic lookup
+    accepts the alternative names of one kernel."""
     sys.path.insert(0, ROOT)
     import bench
     st = {"sga_scan_fwd_down": 0.07, "sga_scan_fwd_up": 0.07, "sga_scan_fwd_right": 0.07, "sga_scan_fwd_left": 0.07,
           "sga_merge_argmax": 0.11, "sga_bwd_scan_down": 0.08, "sga_bwd_scan_up": 0.08, "sga_bwd_scan_right": 0.07,
-          "sga_bwd_scan_left": 0.07, "sga_bwd_point": 0.29, "lga_fwd_pass": 0.09, "lga_bwd_pass": 0.19}
+          "sga_bwd_scan_left": 0.07, "sga_bwd_point": 0.29, "lga_fwd_pass": 0.09, "lga_bwd_pass": 0.19,
+          "lga_fwd_apply_1": 0.091, "lga_fwd_apply_2": 0.089, "lga_bwd_filter_grad_2": 0.095, "lga_bwd_data_2": 0.09,
+          "lga_bwd_filter_grad_1": 0.105, "lga_bwd_data_1": 0.09}
     r = bench.roofline_from_stages(st)
     fam = {f["kernel"]: f for f in r["families"]}
     assert set(fam) == {"sga_scan_fwd", "sga_merge_argmax", "sga_bwd_scan", "sga_bwd_point",
@@ -141,9 +145,17 @@ def test_bench_roofline_object_from_stage_times():
     assert fam["sga_merge_argmax"]["avg_launch_ms"] == 0.11 and fam["sga_bwd_point"]["avg_launch_ms"] == 0.29
     assert abs(fam["sga_scan_fwd"]["step_ms"] - 0.28) < 1e-9 and fam["sga_scan_fwd"]["launches_per_step"] == 4
     assert fam["lga_apply (fwd pass)"]["bound"] == "fp32" and fam["sga_bwd_point"]["bound"] == "hbm"
-    # dominant family = largest share of the step; its fraction against its binding bound
-    assert r["kernel"] == "lga_apply+filter_grad (bwd pass)" and r["bound"].startswith("fp32")
-    assert abs(r["frac"] - 2 * bench._LGA_PASS_FLOPS / 0.19e-3 / 1e12 / bench.FP32_PEAK_TFLOPS) < 1e-3
+    # headline = the single largest kernel, by the name rocprofv3 prints, against ITS bound
+    assert r["kernel"].startswith("sga_bwd_point<") and r["largest_kernel"] == r["kernel"] and r["bound"] == "hbm"
+    assert abs(r["frac"] - (2 * bench._V + 8 * bench._G) / 0.29e-3 / 1e9 / bench.HBM_PEAK_GBS) < 1e-3
+    assert len(r["kernels"]) == 16 and abs(sum(k["share"] for k in r["kernels"]) - 1.0) < 1e-3
+    by_stage = {k["stage"]: k for k in r["kernels"]}
+    assert by_stage["lga_bwd_filter_grad_1"]["kernel"].startswith("lga_filter_grad_pp_gypx") and by_stage["lga_bwd_filter_grad_1"]["bound"] == "fp32"
+    assert abs(by_stage["lga_fwd_apply_1"]["frac"] - bench._LGA_PASS_FLOPS / 0.091e-3 / 1e12 / bench.FP32_PEAK_TFLOPS) < 1e-3
+    # the family with the largest share of the step, and the one furthest below its bound, are named beside it
+    assert r["dominant_family"]["kernel"] == "lga_apply+filter_grad (bwd pass)"
+    assert abs(r["dominant_family"]["frac"] - 2 * bench._LGA_PASS_FLOPS / 0.19e-3 / 1e12 / bench.FP32_PEAK_TFLOPS) < 1e-3
+    assert r["worst_family"]["kernel"] == "sga_bwd_scan"
     assert r["mfma"]["used"] is False and r["mfma"]["mfma_utilisation"] == 0.0
     assert r["achievable"]["hbm_copy_GBs"] < bench.HBM_PEAK_GBS and r["achievable"]["fp32_pk_fma_TFLOPs"] < bench.FP32_PEAK_TFLOPS
     kern = {"sga_bwd_point<4, false>": {"read_bytes": 10, "write_bytes": 5}}
