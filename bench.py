@@ -291,7 +291,7 @@ def pmc_traffic_tree():
 
 def pmc_traffic():
     """Per-kernel traffic (bytes per dispatch at the L2 <-> fabric boundary) from the committed rocprofv3 --pmc
-    passes (profiles/traffic_pmc.json, made by scripts/gpu_pmc2.sh + scripts/pmc_traffic.py on an MI355X with
+    passes (profiles/traffic_pmc.json, made by `scripts/gpu_session.sh <tag> pmc` + scripts/pmc_traffic.py on an MI355X with
     this workload).  Counters cannot be collected inside the timed run, hence the file; None when it is absent."""
     fn = os.path.join(ROOT, "profiles", "traffic_pmc.json")
     try:

@@ -1,7 +1,12 @@
 #!/bin/bash
 # One GPU session.  gpurun --timeout N -- 'bash scripts/gpu_session.sh <tag> [parts]'
-#   parts: any of  ubench tests smoke bench prof pmc modeltests model nofind census ab  (default: tests smoke bench prof model)
-#   census: the fused-vs-stock op censuses (scripts/bench_census*.py, bench_residual_tail.py);  ab: scripts/ab_step.py $AB_ARGS
+#   parts: any of  ubench tests smoke bench prof pmc pmcwave modeltests model nofind census ab stages  (default: tests smoke bench prof model)
+#   pmc: memory-side passes over the step -> traffic_pmc.json;  pmcwave: wave-level issue / wait / LDS / MFMA counter sets over
+#   scripts/prof_stage.py $STAGE (default: step);  census: the fused-vs-stock op censuses (scripts/bench_census*.py,
+#   bench_residual_tail.py);  ab: scripts/ab_step.py $AB_ARGS (same-box whole-step A/B of library builds / options);
+#   stages: scripts/ab_lga_stages.py + ab_sga_stages.py $AB_ARGS (every kernel of the step in sequence, per library)
+# (The one-session scripts of rounds 4-5 -- gpu_s1..s8, gpu_pmc*, gpu_diag*, gpu_sweep, gpu_ab -- are these parts now; what each
+# of them measured is in profiles/ under its tag.)
 # Everything worth keeping goes to gpurun_out/<tag>/ (merged back into the dev container).
 TAG=${1:-r2}
 PARTS=${2:-"tests smoke bench prof model"}
@@ -66,6 +71,27 @@ fi
 if has ab; then
   echo "== same-box whole-step A/B: ab_step.py $AB_ARGS"
   timeout 900 python scripts/ab_step.py $AB_ARGS > $OUT/ab_step.txt 2> $OUT/ab_step.err; echo "ab rc=$?"; cat $OUT/ab_step.txt; tail -3 $OUT/ab_step.err
+fi
+if has pmcwave; then
+  echo "== wave-level counter passes over prof_stage.py ${STAGE:-step} (at most four TCC / TCP counters per pass: larger sets hung in round 3)"
+  mkdir -p $OUT/pmcwave
+  ( cd /tmp; i=0
+    for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+               "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
+               "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmcwave/p$i -o pmc --output-format csv -- python $ROOT/scripts/prof_stage.py ${STAGE:-step} 3 > $OUT/pmcwave/p$i.log 2>&1
+      echo "pmcwave set $i rc=$?"
+    done )
+  python scripts/pmc_summary.py $OUT/pmcwave > $OUT/pmcwave/summary.txt 2>&1
+  find $OUT/pmcwave -name '*.csv' -size +2M -delete 2>/dev/null
+  grep -c "^==" $OUT/pmcwave/summary.txt
+fi
+if has stages; then
+  echo "== every kernel of the step in sequence, per library: $AB_ARGS"
+  timeout 600 python scripts/ab_lga_stages.py $AB_ARGS > $OUT/ab_lga_stages.txt 2>&1; echo "lga stages rc=$?"; grep -v amdgpu.ids $OUT/ab_lga_stages.txt | cut -c1-400
+  timeout 600 python scripts/ab_sga_stages.py $AB_ARGS > $OUT/ab_sga_stages.txt 2>&1; echo "sga stages rc=$?"; grep -v amdgpu.ids $OUT/ab_sga_stages.txt | cut -c1-400
 fi
 if has modeltests; then
   echo "== model tests (reference models on the drop-in, GPU vs CPU-oracle twin)"

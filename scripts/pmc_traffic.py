@@ -1,4 +1,4 @@
-"""Per-kernel HBM-side traffic from the memory-side PMC passes (scripts/gpu_pmc2.sh):
+"""Per-kernel HBM-side traffic from the memory-side PMC passes (scripts/gpu_session.sh <tag> pmc):
    bytes = TCC_EA0_RDREQ_128B*128 + RDREQ_64B*64 + RDREQ_32B*32 (+ other reads * 64) and WRREQ_64B*64 + other writes * 32,
    mean per dispatch.  (Request counts x request size instead of FETCH_SIZE/WRITE_SIZE: MI355X_MICROARCH.md notes that
    FETCH_SIZE tallies 128-byte requests at 64 B on gfx950.)  Infinity-Cache hits are included: this is traffic at the

@@ -214,7 +214,7 @@ def test_traffic_file_names_the_tree_it_was_measured_on():
     import bench
     assert bench.pmc_traffic() is not None
     assert bench.pmc_traffic_tree() == bench.csrc_tree_hash(), \
-        "profiles/traffic_pmc.json was measured on other kernel sources: regenerate it (scripts/gpu_s3.sh) or say why not"
+        "profiles/traffic_pmc.json was measured on other kernel sources: regenerate it (scripts/gpu_session.sh <tag> pmc) or say why not"
     r = bench.roofline_from_stages({"sga_scan_fwd_down": 0.07, "sga_scan_fwd_up": 0.07, "sga_scan_fwd_right": 0.07, "sga_scan_fwd_left": 0.07,
                                     "sga_merge_argmax": 0.11, "sga_bwd_scan_down": 0.08, "sga_bwd_scan_up": 0.08, "sga_bwd_scan_right": 0.07,
                                     "sga_bwd_scan_left": 0.07, "sga_bwd_point": 0.29, "lga_fwd_pass": 0.09, "lga_bwd_pass": 0.19})
