@@ -193,7 +193,8 @@ def test_apply_paired_argument_errors(sim):
 
 @pytest.mark.parametrize("mode", ["guard_end", "guard_start", "late_reversed"])
 @pytest.mark.parametrize("shape", [(1, 9, 3, 36), (1, 12, 4, 40), (2, 21, 5, 68), (1, 1, 3, 34), (1, 2, 2, 2), (1, 26, 2, 6),
-                                   (1, 40, 3, 32), (1, 41, 7, 64), (3, 12, 4, 40), (4, 2, 2, 2)])
+                                   (1, 40, 3, 32), (1, 41, 7, 64), (3, 12, 4, 40), (4, 2, 2, 2),
+                                   (1, 9, 7, 100), (2, 6, 8, 70)])      # (tiles whose every tap is inside the image: seeded accumulators)
 def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, mode):
     """ganet_lga_filter_grad_paired (ABI v7): gf of one pass with x (or gy) in the pair-interleaved layout, write and
     accumulate mode; batches of three and four with an even D."""
@@ -226,7 +227,7 @@ def test_filter_gradient_on_pair_interleaved_x(sim, port_oracle, shape, mode):
 
 @pytest.mark.parametrize("mix", [1, 3, 0])
 @pytest.mark.parametrize("shape", [(1, 9, 3, 36), (2, 21, 5, 68), (1, 40, 3, 32), (1, 41, 7, 64), (1, 2, 2, 2), (3, 12, 4, 40), (4, 2, 2, 2), (1, 47, 2, 100),
-                                   (1, 3, 2, 4), (1, 5, 1, 8), (2, 7, 9, 12), (1, 1, 1, 4), (1, 2, 3, 16)])      # (planar staging of the API-layout operands, narrow images)
+                                   (1, 11, 7, 100), (1, 3, 2, 4), (1, 5, 1, 8), (2, 7, 9, 12), (1, 1, 1, 4), (1, 2, 3, 16)])      # (planar staging of the API-layout operands, narrow images)
 def test_two_pass_chain_with_pair_interleaved_intermediate(sim, port_oracle, shape, mix):
     """The call sequence of Lga2Function (default; GANET_LGA_PAIRED=0 switches it off) (ganet_amd/functions/GANet.py: _LgaChain): forward
     x -> t1 (interleaved) -> y; backward gf = gF(t1 interleaved, gy); g_t1 (interleaved) = gX(gy); gf += gF(x, g_t1); gx = gX(g_t1)."""
