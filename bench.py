@@ -180,7 +180,7 @@ _FAMILY_KERNELS = {
                      ["sga_row_bwdg<2, 32, 4, 1, true, false, 64, 9>"], ["sga_row_bwdg<2, 32, 4, 1, false, false, 64, 9>"]],
     "sga_bwd_point": [["sga_bwd_point<4, false, true>|sga_bwd_point<4, false>|sga_bwd_point<4, false, false>"]],   # (a|b: first name found)
     # (workgroup-ring kernels = the default, GANET_LGA_WAVE=2; the one-wave names as alternatives: whichever the traffic file holds)
-    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pp_xp<2, 3, 0>",
+    "lga_apply+filter_grad (bwd pass)": [["lga_filter_grad_pair_xp<5>|lga_filter_grad_pp_xp<2, 3, 0>",
                                           "lga_apply_pp_wxo<2, true, false>|lga_apply_pp_xo<2, true, false>"],
                                          ["lga_filter_grad_pp_gypx<2, 3, 0>",
                                           "lga_apply_pp_wpi<2, true, false>|lga_apply_pp_pi<2, true, false>"]],
@@ -223,7 +223,7 @@ _STAGE_KERNELS = {
     "sga_bwd_point": "sga_bwd_point<4, false, true>|sga_bwd_point<4, false>|sga_bwd_point<4, false, false>",
     "lga_fwd_apply_1": "lga_apply_pp_wxo<2, false, false>|lga_apply_pp_xo<2, false, false>",
     "lga_fwd_apply_2": "lga_apply_pp_wpi<2, false, false>|lga_apply_pp_pi<2, false, false>",
-    "lga_bwd_filter_grad_2": "lga_filter_grad_pp_xp<2, 3, 0>",
+    "lga_bwd_filter_grad_2": "lga_filter_grad_pair_xp<5>|lga_filter_grad_pp_xp<2, 3, 0>",
     "lga_bwd_data_2": "lga_apply_pp_wxo<2, true, false>|lga_apply_pp_xo<2, true, false>",
     "lga_bwd_filter_grad_1": "lga_filter_grad_pp_gypx<2, 3, 0>",
     "lga_bwd_data_1": "lga_apply_pp_wpi<2, true, false>|lga_apply_pp_pi<2, true, false>",

@@ -64,7 +64,7 @@ int check_launch(const char *what)
 struct Options {
   std::atomic<int> sga_tiled{GA_SGA_TILED_DEFAULT};  // SGA backward: the vertical directions' adjoint volumes G_down / G_up in the private tiled layout
                                     // of sga_col_kernels.h (1; where W % 16 == 0 and H % 4 == 0) or in the API layout (0)
-  std::atomic<int> lga_wave{2};     // LGA kernel family (radius <= 2): 2 plane-pair kernels, the forward / data-backward with ONE x ring per 256-thread workgroup on 32 x 8 tiles and a barrier per plane pair (lga_apply_pp_w*; default: whole step -1.4 ... -3.5 % over five boxes against 1, profiles/r8*_ab_step*; where W % 4 != 0 on API-layout x: as 1), 1 plane-pair kernels with one ring per wave on 32 x 2 tiles (lga_apply_pp_* / lga_filter_grad_pp_*: what the filter gradient always runs; its workgroup form was measured: no gain, removed), 0 the 256-thread tile kernels (any radius; the general fallback)
+  std::atomic<int> lga_wave{2};     // LGA kernel family (radius <= 2): 2 plane-pair kernels, the forward / data-backward with ONE x ring per 256-thread workgroup on 32 x 8 tiles and a barrier per plane pair (lga_apply_pp_w*; default: whole step -1.4 ... -3.5 % over five boxes against 1, profiles/r8*_ab_step*; where W % 4 != 0 on API-layout x: as 1), 1 plane-pair kernels with one ring per wave on 32 x 2 tiles (lga_apply_pp_* / lga_filter_grad_pp_*).  The filter gradient under 2: where x is pair-interleaved (the second pass of an LGA2) the taps of a 32 x 2 tile are split over a WAVE PAIR that shares the rings (lga_filter_grad_pair_xp: five waves per SIMD instead of three, the launch -7 %, round 6 profiles/r9k_*, r9l_*); with an API-layout x it runs the one-wave kernel in both settings (its wave-pair form lost +3 %, its four-wave ring form of round 5 was no gain: both removed).  0 the 256-thread tile kernels (any radius; the general fallback)
   std::atomic<int> lga_mix{1};      // plane-pair forward / data-backward: mixed item list (whole tiles + segments of the rest); 0 off, 1 on (measured: forward pass 0.103 -> 0.0955 ms, profiles/r3a_*), n > 1: n SIMDs assumed (tests)
   std::atomic<int> lga_segs{0};     // depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
   std::atomic<int> wide_col{1};     // vertical scans: LDS-staged column blocks with one wavefront per column (1,024-thread blocks): 1 for inputs with few column blocks and D >= 96 (measured on [1,1,192,240,624]: forward 0.33 -> 0.21 ms, adjoint 0.52 -> 0.40, profiles/r3a_check_wide_col.txt), 0 never, 2 whenever the kernel applies (tests)
@@ -570,6 +570,12 @@ LgaSegMix lga_items(int W, int H, int B, int D, bool whole_only, i64 *items, boo
 }
 
 #ifndef GA_LGA_PLANAR
+#ifndef GA_FGP_DEFAULT
+#define GA_FGP_DEFAULT 1  // (0: a build whose GANET_LGA_WAVE=2 keeps the one-wave filter gradient -- same-box A/B builds, scripts/build_variants.py)
+#endif
+#ifndef GA_FGP_WPS
+#define GA_FGP_WPS 5      // waves per SIMD the wave-pair filter gradient is compiled for
+#endif
 #define GA_LGA_PLANAR 1     // API-layout operands of the plane-pair kernels staged planar by 16-byte copies where W % 4 == 0
 #endif
 template <int R>
@@ -669,7 +675,9 @@ int launch_lga_gf_paired(const float *x, const float *gy, float *gf, int B, int 
   sg.nseg = 1; sg.seg_len = D;
   const i64 items = (i64)sg.tiles_x * sg.tiles_y * B;
   if (items >= (1ll << 31)) return fail(GANET_E_UNSUPPORTED, "ganet_lga_filter_grad_paired: too many tiles");
-  if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
+  const bool fg_pair = GA_FGP_DEFAULT && opts().lga_wave >= 2;      // the workgroup forms: here the taps of a tile split over a wave pair (lga_filter_grad_pair.inc)
+  if (x_paired && fg_pair) GA_LAUNCH((lga_filter_grad_pair_xp<GA_FGP_WPS>), dim3((unsigned)items), dim3(128), st, x, gy, gf, geo, sg, acc);
+  else if (x_paired) GA_LAUNCH((lga_filter_grad_pp_xp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else if (GA_LGA_PLANAR && W % 4 == 0) GA_LAUNCH((lga_filter_grad_pp_gypx<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   else GA_LAUNCH((lga_filter_grad_pp_gyp<2, 3, 0>), dim3((unsigned)items), dim3(64), st, x, gy, gf, geo, sg, acc);
   return check_launch("lga filter grad (plane pairs, interleaved volume)");

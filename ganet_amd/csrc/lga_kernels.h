@@ -892,6 +892,52 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #endif
 }
 
+// The same for N = 3 or N = 2 neighbouring cells of a window row (lga_filter_grad_pair.inc splits the centre row between its two
+// waves: columns 0 .. 2 and 3, 4).  Dependent updates of a P stay >= 4 instructions apart.
+template <int WAIT, int N>
+GA_DEV void lga_row_fg_n(f2 *Pr, f2 *Qr, const f2 *X, f2 Ga, f2 Gn, f2 Gc)
+{
+  static_assert(N == 2 || N == 3, "partial rows of 2 or 3 cells");
+#if defined(GA_HIPSIM)
+  if (WAIT >= 0) hipsim::lgkmcnt(WAIT);
+  for (int b2 = 0; b2 < N; b2++) {
+    const int bb = N - 1 - b2;
+    Pr[bb] = fma2(mk2(X[bb].x, X[bb].x), Ga, Pr[bb]);
+    Qr[bb] = fma2(X[bb], Gc, Qr[bb]);
+  }
+  for (int b2 = 0; b2 < N; b2++) {
+    const int bb = N - 1 - b2;
+    Pr[bb] = fma2(mk2(X[bb].y, X[bb].y), mk2(Gn.y, Gn.x), Pr[bb]);
+  }
+#else
+#define GA_FGN_PX(p, x, ga) "v_pk_fma_f32 %" #p ", %" #x ", %" #ga ", %" #p " op_sel_hi:[0,1,1]\n\t"
+#define GA_FGN_PY(p, x, gn) "v_pk_fma_f32 %" #p ", %" #x ", %" #gn ", %" #p " op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+#define GA_FGN_Q(q, x, gc) "v_pk_fma_f32 %" #q ", %" #x ", %" #gc ", %" #q "\n\t"
+  if constexpr (N == 3) {
+    // operands: 0..2 = P, 3..5 = Q, 6..8 = X, 9 = Ga, 10 = Gn, 11 = Gc, 12 = WAIT
+#define GA_FGN_ROW GA_FGN_PX(2, 8, 9) GA_FGN_Q(5, 8, 11) GA_FGN_PX(1, 7, 9) GA_FGN_Q(4, 7, 11) GA_FGN_PX(0, 6, 9) GA_FGN_Q(3, 6, 11) \
+                   GA_FGN_PY(2, 8, 10) GA_FGN_PY(1, 7, 10) GA_FGN_PY(0, 6, 10)
+#define GA_FGN_OPS : "+v"(Pr[0]), "+v"(Pr[1]), "+v"(Pr[2]), "+v"(Qr[0]), "+v"(Qr[1]), "+v"(Qr[2]) \
+                   : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(Ga), "v"(Gn), "v"(Gc), "n"(WAIT >= 0 ? WAIT : 0)
+    if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%12)\n\t" GA_FGN_ROW GA_FGN_OPS);
+    else asm(GA_FGN_ROW GA_FGN_OPS);
+#undef GA_FGN_ROW
+#undef GA_FGN_OPS
+  } else {
+    // operands: 0..1 = P, 2..3 = Q, 4..5 = X, 6 = Ga, 7 = Gn, 8 = Gc, 9 = WAIT
+#define GA_FGN_ROW GA_FGN_PX(1, 5, 6) GA_FGN_Q(3, 5, 8) GA_FGN_PX(0, 4, 6) GA_FGN_Q(2, 4, 8) GA_FGN_PY(1, 5, 7) GA_FGN_PY(0, 4, 7)
+#define GA_FGN_OPS : "+v"(Pr[0]), "+v"(Pr[1]), "+v"(Qr[0]), "+v"(Qr[1]) : "v"(X[0]), "v"(X[1]), "v"(Ga), "v"(Gn), "v"(Gc), "n"(WAIT >= 0 ? WAIT : 0)
+    if constexpr (WAIT >= 0) asm volatile("s_waitcnt lgkmcnt(%9)\n\t" GA_FGN_ROW GA_FGN_OPS);
+    else asm(GA_FGN_ROW GA_FGN_OPS);
+#undef GA_FGN_ROW
+#undef GA_FGN_OPS
+  }
+#undef GA_FGN_PX
+#undef GA_FGN_PY
+#undef GA_FGN_Q
+#endif
+}
+
 // ---- filter backward, PLANE-PAIR packing -------------------------------------------------------------------
 // Same staging as lga_apply_pp (plane pairs X = (x[2m], x[2m+1]) interleaved in LDS, one ds_read_b64 per window position),
 // the lane's own gy values through a second ring (one dword copy per plane, [plane][lane]).  With g_k = gy[k] of the pixel:
@@ -940,6 +986,12 @@ GA_DEV void lga_row_fg(f2 (&Pr)[5], f2 (&Qr)[5], const f2 (&X)[5], f2 Ga, f2 Gn,
 #define GA_FG_SLOT 512
 #define GA_FG_NDC 2
 #include "lga_filter_grad_pp.inc"
+
+// the taps of a tile split over a wave pair (lga_filter_grad_pair.inc): the two filter gradients of an LGA2's backward
+#define GA_FGP_NAME lga_filter_grad_pair_xp
+#define GA_FGP_XP 1
+#define GA_FGP_GYP 0
+#include "lga_filter_grad_pair.inc"
 
 // ---- filter backward --------------------------------------------------------------
 // gf[b,t,i,j] (+)= sum_d gy[b,d,i,j] * xs(d+dd, i+a, j+b)   (centre replacement)

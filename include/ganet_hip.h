@@ -310,7 +310,10 @@ int ganet_selftest_dpp_wave(int *scratch_dev, int *host_out, void *stream);
  *                         tiles | the same with the forward / data-backward kernels on ONE ring per 256-thread workgroup (32 x 8
  *                         tiles: the halo'd tile staged once for four waves, 12 rows fetched for 8 instead of 24; a barrier per
  *                         plane pair).  Default 2 (whole step -1.4 ... -3.5 % in five A/Bs on four boxes against 1, profiles/r8*_ab_step*).
- *                         The filter gradient runs one ring per wave in both (its workgroup form: measured, no gain, removed)
+ *                         The filter gradient: under 2, where its x is pair-interleaved (an LGA2's second pass), the 75 taps of a 32 x 2
+ *                         tile are split over a wave pair that shares the x and gy rings (five waves per SIMD instead of three: its launch
+ *                         -7 %, profiles/r9k_*, r9l_*); with an API-layout x one ring per wave in both (the wave-pair form lost there,
+ *                         the four-wave ring form of round 5 was no gain: removed)
  *   GANET_LGA_SEGS = n    depth segments per tile for the plane-pair forward / data-backward (0 = automatic)
  *   GANET_LGA_MIX=0|1|n   the same kernels with a MIXED item list: whole tiles first (a whole number per SIMD), the remaining
  *                         tiles cut into depth segments, at most one segment per SIMD -- the waves of a SIMD share one VALU, so

@@ -357,3 +357,87 @@ def test_lga_workgroup_ring_bit_identical_to_one_wave_kernels(sim, port_oracle, 
         sim.set_option("GANET_LGA_SEGS", 0)
 
 
+
+
+# ---- the filter gradient with a tile's taps split over a wave pair (GANET_LGA_WAVE=2, x pair-interleaved: lga_filter_grad_pair.inc) ------
+# Two waves on the same 64 pixels share one x ring and one gy ring; each issues half of a step's copies, waits for ITS half with a counted
+# vmcnt and meets the other at one workgroup barrier per pair-step.  The chains above run it wherever they take the pair-interleaved
+# intermediate under GANET_LGA_WAVE=2; here it is taken alone: every schedule the emulator has, and the counted wait must be tight.
+def _fg_pair_once(sim, port_oracle, shape, acc_twice=True):
+    B, D, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    f = pc.l1norm(rng.standard_normal((B, 75, H, W)), 1)
+    _, want = port_oracle.lga_backward(x, f, gy, 2)
+    dev = pc.NumpyDev("end")
+    xp, dgy, gf = dev.to(pc.to_paired(x)), dev.to(gy), dev.empty(f.shape)
+    sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, 1, 0, None)
+    e = float(np.abs(gf - want).max()) if np.isfinite(gf).all() else float("inf")
+    if acc_twice:
+        sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 1, 1, 0, None)
+        e = max(e, 0.5 * float(np.abs(gf - 2 * want).max()) if np.isfinite(gf).all() else float("inf"))
+    return e
+
+
+_FG_PAIR_SHAPES = [(1, D, 3, 36) for D in (1, 2, 3, 4, 9, 10, 11, 12, 13, 21, 22)] + \
+                  [(2, 21, 5, 68), (1, 26, 2, 6), (1, 41, 7, 64), (1, 9, 7, 100), (4, 2, 2, 2), (1, 33, 6, 72), (3, 12, 4, 40)]
+
+
+@pytest.mark.parametrize("mode", ["plain", "late", "late_reversed", "first_wave_ahead", "last_wave_ahead"])
+def test_filter_gradient_wave_pair_under_every_schedule(sim, port_oracle, mode):
+    opts = {"plain": {}, "late": {"HIPSIM_LATE_DMA": 1}, "late_reversed": {"HIPSIM_LATE_DMA": 1, "HIPSIM_LANE_ORDER": 1},
+            "first_wave_ahead": {"HIPSIM_LATE_DMA": 1, "HIPSIM_WAVE_GREEDY": 1},
+            "last_wave_ahead": {"HIPSIM_LATE_DMA": 1, "HIPSIM_WAVE_GREEDY": 1, "HIPSIM_LANE_ORDER": 1}}[mode]
+    assert sim.get_option("GANET_LGA_WAVE") == 2
+    for k, v in opts.items():
+        sim.set_option(k, v)
+    try:
+        for shape in _FG_PAIR_SHAPES:
+            assert _fg_pair_once(sim, port_oracle, shape) < 3e-5, shape
+    finally:
+        for k in opts:
+            sim.set_option(k, 0)
+
+
+def test_filter_gradient_wave_pair_equals_one_wave_kernel_bit_for_bit(sim, port_oracle):
+    """same FMAs per tap in the same order, the centre sums handed over exactly: the two forms agree to the bit"""
+    res = []
+    try:
+        for wave in (1, 2):
+            sim.set_option("GANET_LGA_WAVE", wave)
+            out = []
+            for shape in [(1, 13, 3, 36), (2, 21, 5, 68), (1, 41, 7, 64), (1, 9, 7, 100)]:
+                B, D, H, W = shape
+                rng = np.random.default_rng(sum(shape))
+                x = rng.standard_normal(shape).astype(np.float32)
+                gy = rng.standard_normal(shape).astype(np.float32)
+                dev = pc.NumpyDev("end")
+                xp, dgy, gf = dev.to(pc.to_paired(x)), dev.to(gy), dev.empty((B, 75, H, W))
+                sim.call("ganet_lga_filter_grad_paired", dev.ptr(xp), dev.ptr(dgy), dev.ptr(gf), B, D, H, W, 2, 0, 1, 0, None)
+                out.append(np.array(gf))
+            res.append(out)
+    finally:
+        sim.set_option("GANET_LGA_WAVE", 2)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+def test_filter_gradient_wave_pair_counted_wait_is_tight(sim, port_oracle):
+    """one operation of slack in the counted vmcnt and the late-landing copies are read before they arrive"""
+    sim.set_option("HIPSIM_LATE_DMA", 1)
+    try:
+        bad = {}
+        for slack in (0, 1):
+            sim.set_option("HIPSIM_VMCNT_SLACK", slack)
+            n = 0
+            for shape in [(1, 41, 7, 64), (1, 33, 6, 72), (1, 21, 3, 36)]:
+                try:
+                    n += not (_fg_pair_once(sim, port_oracle, shape, acc_twice=False) < 3e-5)
+                except Exception:          # noqa: BLE001  (the emulator aborts a read of an unlanded slot in some modes)
+                    n += 1
+            bad[slack] = n
+        assert bad[0] == 0 and bad[1] > 0, bad
+    finally:
+        sim.set_option("HIPSIM_VMCNT_SLACK", 0)
+        sim.set_option("HIPSIM_LATE_DMA", 0)
