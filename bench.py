@@ -16,10 +16,13 @@ path has -- the 26.3 MB fp32 gradient all-reduce of GANet-deep -- over RCCL and 
 `value`).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family (largest share of the step) against its BINDING bound -- HBM bandwidth for the
-                SGA families, fp32 FMA rate for the LGA families -- from per-stage HIP-event timings taken on
-                the launch stream after the timed region; `families` lists every family with both fractions; the unit's
-                measured traffic (PMC) beside its algorithmic bytes
+  roofline      ONE kernel under the name rocprofv3 prints for it -- the launch with the largest share of the step -- against its
+                binding bound (HBM bandwidth for the SGA kernels, fp32 FMA rate for the LGA kernels), from HIP-event
+                timings of every kernel in place on the launch stream after the timed region; `kernels` lists all 16 launches,
+                `families` the six kernel families with both fractions, `dominant_family` / `worst_family` name the family with
+                the largest share and the one furthest below its bound; the measured traffic (PMC) beside the algorithmic bytes
+  value         the contract's protocol: W warm-up replays + K timed ones straight after the graph capture; `value_settled` = the
+                same K steps after 0.1 s more of replays (the clock ramp after the capture is worth ~1.5 %), `value_1s` sustained
   cpu_baseline  the CPU checker (oracle/_ref = the reference's own kernel bodies when the prebuilt
                 .so is present, else the C restatement) timed on this box's host cores on ONE
                 cost volume of the same workload
@@ -45,7 +48,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SGA_SHAPE = (1, 32, 65, 80, 208)
 LGA_SHAPE = (1, 193, 240, 624)
 RADIUS = 2
-SETTLE_S = 0.1                 # replays between the graph capture (GPU idle) and the W warm-up steps: see main()
+SETTLE_S = 0.1                 # extra replays before the SECOND measurement (`value_settled`): see main()
 
 # algorithmic bytes (SURVEY.md 8d / BASELINE.md 2): inputs read once + outputs written once
 _V = 4 * 1 * 32 * 65 * 80 * 208
@@ -573,9 +576,8 @@ def main():
     if graph is not None:
         # The GPU sat idle while the graph was captured and needs ~30 ms of work to be back at its running clocks: the first
         # 20-step region after a capture reads 1.3 % slower than every later one, and so does one after 0.5 s of idling
-        # (scripts/diag_bench_timing.py, profiles/r7k_diag_bench_timing.txt).  W = 5 warm-up steps are 8 ms, so the device is
-        # brought back to its running state first (replays for SETTLE_S seconds, reported in the line); then the W warm-up
-        # steps and the K timed ones as the contract has them.
+        # (scripts/diag_bench_timing.py, profiles/r7k_diag_bench_timing.txt); W = 5 warm-up steps are 8 ms.  Rounds 4 - 5 therefore
+        # replayed for SETTLE_S seconds first and printed THAT measurement as `value`; since round 6:
         # `value` IS the contract's protocol: W warm-up replays and K timed ones straight after the capture (`--warmup 5`
         # means what the driver typed).  The same K steps once the device is back at its running clocks (SETTLE_S seconds of
         # replays, then W + K again) are reported beside it as `value_settled`; `value_1s` is the sustained rate.
